@@ -1,0 +1,902 @@
+// libsr3hip.so — C-ABI (include/sr3hip.h), context, UNet graph builder and the DDPM sampler loop.
+//
+// The graph builder restates UNet.__init__ (reference model/sr/sr3_modules/unet.py:161-233) so the
+// parameter names are the reference's state_dict keys; forward() restates UNet.forward (:235-265)
+// and ResnetBlock/SelfAttention.forward (:105-110, :123-142) as a sequence of HIP launches.
+#include "../../include/sr3hip.h"
+#include "sr3_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace sr3;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+#define HIP_OK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));          \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+enum ParamKind { P_CONV, P_PLAIN };
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    ParamKind kind = P_PLAIN;
+    int cout = 0, cin = 0, ks = 0, cin_pad = 0;  // P_CONV
+    float *dev = nullptr;                        // device storage (kernel layout)
+    size_t dev_floats = 0;
+    bool owns = true;                            // false: a view into a concatenated buffer
+    bool loaded = false;
+};
+
+struct GNRef { int gamma = -1, beta = -1, C = 0; };
+struct ConvRef { int w = -1, b = -1, cin = 0, cout = 0, ks = 0, cin_pad = 0; };
+
+struct ResBlock {
+    int cin = 0, cout = 0;
+    GNRef gn1, gn2, agn;
+    ConvRef c1, c2, res, qkv, aout;
+    int nf_off = 0;  // offset into the concatenated FeatureWiseAffine output
+    bool has_res = false, attn = false;
+};
+
+enum ModKind { M_CONV_IN, M_RES, M_DOWN, M_UP };
+struct Module {
+    ModKind kind;
+    ResBlock rb;
+    ConvRef conv;
+    // workspace (set by ensure_workspace)
+    float *out = nullptr;     // module output
+    float *rb_out = nullptr;  // ResBlock output before attention (== out if no attention)
+    int oc = 0, oh = 0, ow = 0;
+};
+
+enum Family { F_CONV = 0, F_GN = 1, F_ATTN = 2, F_EMBED = 3, F_MISC = 4 };
+
+struct ProfRec { int fam; hipEvent_t a, b; double flops; };
+
+} // namespace
+
+struct sr3_ctx {
+    sr3_unet_cfg cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<Param> params;
+    std::vector<Module> mods;   // downs ‖ mid ‖ ups
+    int n_downs = 0, n_mid = 0;
+    GNRef final_gn;
+    ConvRef final_conv;
+    int mlp_w1 = -1, mlp_b1 = -1, mlp_w2 = -1, mlp_b2 = -1;
+    float *nfw = nullptr, *nfb = nullptr;  // concatenated FeatureWiseAffine linears
+    int nf_total = 0;
+    int in_pad = 0;     // in_channel padded to 32
+    int c_max = 0;      // widest GroupNorm input
+    uint64_t weight_bytes = 0;
+
+    // workspace for one (B, H, W)
+    int wB = 0, wH = 0, wW = 0;
+    char *arena = nullptr;
+    uint64_t arena_bytes = 0;
+    float *x0 = nullptr;        // [B][HW][in_pad]: cond ‖ x ‖ zero pad (the UNet input and sampler state)
+    float *h1 = nullptr, *rbuf = nullptr, *qkvb = nullptr, *aob = nullptr;
+    float *gscale = nullptr, *gshift = nullptr, *gpart = nullptr;
+    float *temb = nullptr, *cbias = nullptr, *eps = nullptr, *nlb = nullptr;
+
+    // schedule
+    int T = 0;
+    std::vector<float> s_nl, s_a, s_b, s_lv, s_c1, s_c2;
+    float *d_nl = nullptr;  // [T+1]
+
+    // sampler state
+    uint64_t seed = 0, image_offset = 0;
+    bool sampling = false;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    double acc_ms[SR3_N_FAMILIES] = {0}, acc_flops[SR3_N_FAMILIES] = {0};
+    int64_t acc_n[SR3_N_FAMILIES] = {0};
+
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void pbegin(int fam) {
+        if (!prof) return;
+        ProfRec r{fam, get_event(), get_event(), 0.0};
+        (void)hipEventRecord(r.a, stream);
+        recs.push_back(r);
+    }
+    void pend(double flops = 0.0) {
+        if (!prof) return;
+        recs.back().flops = flops;
+        (void)hipEventRecord(recs.back().b, stream);
+    }
+    void pflush() {
+        if (recs.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto &r : recs) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            acc_ms[r.fam] += ms;
+            acc_flops[r.fam] += r.flops;
+            acc_n[r.fam] += 1;
+            ev_pool.push_back(r.a);
+            ev_pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// graph construction (unet.py:161-233)
+// ---------------------------------------------------------------------------------------------
+int add_param(sr3_ctx *c, const std::string &name, std::vector<int64_t> shape, ParamKind kind = P_PLAIN) {
+    Param p;
+    p.name = name;
+    p.shape = std::move(shape);
+    p.kind = kind;
+    c->params.push_back(p);
+    return (int)c->params.size() - 1;
+}
+
+ConvRef add_conv(sr3_ctx *c, const std::string &prefix, int cin, int cout, int ks, bool bias) {
+    ConvRef r;
+    r.cin = cin; r.cout = cout; r.ks = ks; r.cin_pad = round_up(cin, 32);
+    r.w = add_param(c, prefix + ".weight", {cout, cin, ks, ks}, P_CONV);
+    Param &p = c->params[r.w];
+    p.cout = cout; p.cin = cin; p.ks = ks; p.cin_pad = r.cin_pad;
+    if (bias) r.b = add_param(c, prefix + ".bias", {cout});
+    return r;
+}
+
+GNRef add_gn(sr3_ctx *c, const std::string &prefix, int C) {
+    GNRef g;
+    g.C = C;
+    g.gamma = add_param(c, prefix + ".weight", {C});
+    g.beta = add_param(c, prefix + ".bias", {C});
+    if (C > c->c_max) c->c_max = C;
+    return g;
+}
+
+Module make_res(sr3_ctx *c, const std::string &prefix, int cin, int cout, bool attn) {
+    Module m;
+    m.kind = M_RES;
+    ResBlock &rb = m.rb;
+    rb.cin = cin; rb.cout = cout; rb.attn = attn;
+    const int inner = c->cfg.inner_channel;
+    const std::string rp = prefix + ".res_block";
+    // registration order of the reference: noise_func, block1, block2, res_conv (unet.py:97-103)
+    int nfw = add_param(c, rp + ".noise_func.noise_func.0.weight", {cout, inner});
+    int nfb = add_param(c, rp + ".noise_func.noise_func.0.bias", {cout});
+    c->params[nfw].owns = false;
+    c->params[nfb].owns = false;
+    rb.nf_off = c->nf_total;
+    c->nf_total += cout;
+    rb.gn1 = add_gn(c, rp + ".block1.block.0", cin);
+    rb.c1 = add_conv(c, rp + ".block1.block.3", cin, cout, 3, true);
+    rb.gn2 = add_gn(c, rp + ".block2.block.0", cout);
+    rb.c2 = add_conv(c, rp + ".block2.block.3", cout, cout, 3, true);
+    rb.has_res = (cin != cout);
+    if (rb.has_res) rb.res = add_conv(c, rp + ".res_conv", cin, cout, 1, true);
+    if (attn) {
+        rb.agn = add_gn(c, prefix + ".attn.norm", cout);
+        rb.qkv = add_conv(c, prefix + ".attn.qkv", cout, 3 * cout, 1, false);
+        rb.aout = add_conv(c, prefix + ".attn.out", cout, cout, 1, true);
+    }
+    return m;
+}
+
+bool in_list(const int *v, int n, int x) {
+    for (int i = 0; i < n; ++i)
+        if (v[i] == x) return true;
+    return false;
+}
+
+int build_graph(sr3_ctx *c) {
+    const sr3_unet_cfg &g = c->cfg;
+    const int inner = g.inner_channel;
+    // noise_level_mlp is registered first (unet.py:177-184)
+    c->mlp_w1 = add_param(c, "noise_level_mlp.1.weight", {4 * inner, inner});
+    c->mlp_b1 = add_param(c, "noise_level_mlp.1.bias", {4 * inner});
+    c->mlp_w2 = add_param(c, "noise_level_mlp.3.weight", {inner, 4 * inner});
+    c->mlp_b2 = add_param(c, "noise_level_mlp.3.bias", {inner});
+
+    int pre = inner, now_res = g.image_size, idx = 0;
+    std::vector<int> feat{pre};
+    {
+        Module m;
+        m.kind = M_CONV_IN;
+        m.conv = add_conv(c, "downs.0", g.in_channel, inner, 3, true);
+        c->mods.push_back(m);
+        idx = 1;
+    }
+    for (int ind = 0; ind < g.n_mults; ++ind) {
+        const bool last = ind == g.n_mults - 1;
+        const bool attn = in_list(g.attn_res, g.n_attn_res, now_res);
+        const int ch = inner * g.channel_mults[ind];
+        for (int k = 0; k < g.res_blocks; ++k) {
+            c->mods.push_back(make_res(c, "downs." + std::to_string(idx++), pre, ch, attn));
+            feat.push_back(ch);
+            pre = ch;
+        }
+        if (!last) {
+            Module m;
+            m.kind = M_DOWN;
+            m.conv = add_conv(c, "downs." + std::to_string(idx++) + ".conv", pre, pre, 3, true);
+            c->mods.push_back(m);
+            feat.push_back(pre);
+            now_res /= 2;
+        }
+    }
+    c->n_downs = (int)c->mods.size();
+    c->mods.push_back(make_res(c, "mid.0", pre, pre, true));
+    c->mods.push_back(make_res(c, "mid.1", pre, pre, false));
+    c->n_mid = 2;
+    idx = 0;
+    for (int ind = g.n_mults - 1; ind >= 0; --ind) {
+        const bool last = ind < 1;
+        const bool attn = in_list(g.attn_res, g.n_attn_res, now_res);
+        const int ch = inner * g.channel_mults[ind];
+        for (int k = 0; k < g.res_blocks + 1; ++k) {
+            const int skip = feat.back();
+            feat.pop_back();
+            if (pre + skip == ch)
+                return fail("up-path ResnetBlock with cin == cout (identity skip over a concatenation) is not supported");
+            c->mods.push_back(make_res(c, "ups." + std::to_string(idx++), pre + skip, ch, attn));
+            pre = ch;
+        }
+        if (!last) {
+            Module m;
+            m.kind = M_UP;
+            m.conv = add_conv(c, "ups." + std::to_string(idx++) + ".conv", pre, pre, 3, true);
+            c->mods.push_back(m);
+            now_res *= 2;
+        }
+    }
+    c->final_gn = add_gn(c, "final_conv.block.0", pre);
+    c->final_conv = add_conv(c, "final_conv.block.3", pre, g.out_channel, 3, true);
+    c->in_pad = round_up(g.in_channel, 32);
+    return 0;
+}
+
+int alloc_weights(sr3_ctx *c) {
+    const int inner = c->cfg.inner_channel;
+    HIP_OK(hipMalloc(&c->nfw, (size_t)c->nf_total * inner * sizeof(float)));
+    HIP_OK(hipMalloc(&c->nfb, (size_t)c->nf_total * sizeof(float)));
+    c->weight_bytes += (uint64_t)c->nf_total * (inner + 1) * sizeof(float);
+    int nf_off = 0;
+    for (auto &p : c->params) {
+        if (!p.owns) {
+            // FeatureWiseAffine weight/bias pairs are registered back to back in module order
+            if (p.shape.size() == 2) {
+                p.dev = c->nfw + (size_t)nf_off * inner;
+                p.dev_floats = (size_t)p.shape[0] * inner;
+            } else {
+                p.dev = c->nfb + nf_off;
+                p.dev_floats = (size_t)p.shape[0];
+                nf_off += (int)p.shape[0];
+            }
+            continue;
+        }
+        size_t n = 1;
+        if (p.kind == P_CONV) n = (size_t)p.ks * p.ks * p.cout * p.cin_pad;
+        else for (auto d : p.shape) n *= (size_t)d;
+        p.dev_floats = n;
+        HIP_OK(hipMalloc(&p.dev, n * sizeof(float)));
+        c->weight_bytes += n * sizeof(float);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+struct Carver {
+    uint64_t off = 0;
+    uint64_t take(uint64_t floats) {
+        const uint64_t o = off;
+        off += (floats * sizeof(float) + 255) / 256 * 256;
+        return o;
+    }
+};
+
+int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
+    if (c->arena && c->wB == B && c->wH == H && c->wW == W) return 0;
+    const sr3_unet_cfg &g = c->cfg;
+    const int div = 1 << (g.n_mults - 1);
+    if (B <= 0 || H <= 0 || W <= 0 || (H % div) || (W % div))
+        return fail("unsupported shape B=%d H=%d W=%d: H and W must be multiples of %d", B, H, W, div);
+    if (c->arena) {
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipFree(c->arena));
+        c->arena = nullptr;
+    }
+    // dry run over the graph for sizes
+    Carver cv;
+    std::vector<uint64_t> out_off(c->mods.size()), rb_off(c->mods.size());
+    uint64_t max_rb = 0, max_qkv = 0, max_ao = 0;
+    int h = H, w = W;
+    for (size_t i = 0; i < c->mods.size(); ++i) {
+        Module &m = c->mods[i];
+        int oc;
+        if (m.kind == M_CONV_IN) { oc = m.conv.cout; }
+        else if (m.kind == M_DOWN) { oc = m.conv.cout; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+        else if (m.kind == M_UP) { oc = m.conv.cout; h *= 2; w *= 2; }
+        else {
+            oc = m.rb.cout;
+            const uint64_t n = (uint64_t)B * h * w * oc;
+            if (n > max_rb) max_rb = n;
+            if (m.rb.attn) {
+                if (3 * n > max_qkv) max_qkv = 3 * n;
+                if (n > max_ao) max_ao = n;
+                if ((long)h * w > 1024) return fail("attention over %d tokens exceeds the 1024-token LDS tile", h * w);
+            }
+        }
+        m.oc = oc; m.oh = h; m.ow = w;
+        const uint64_t n = (uint64_t)B * h * w * oc;
+        out_off[i] = cv.take(n);
+        rb_off[i] = (m.kind == M_RES && m.rb.attn) ? cv.take(n) : out_off[i];
+    }
+    if (h != H || w != W) return fail("internal: UNet does not return to the input resolution");
+    const uint64_t HW = (uint64_t)H * W;
+    const uint64_t o_x0 = cv.take((uint64_t)B * HW * c->in_pad);
+    const uint64_t o_h1 = cv.take(max_rb), o_r = cv.take(max_rb);
+    const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
+    const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
+    const uint64_t o_gp = cv.take(gn_workspace_floats(B, g.norm_groups));
+    const uint64_t o_te = cv.take((uint64_t)B * g.inner_channel);
+    const uint64_t o_cb = cv.take((uint64_t)B * c->nf_total);
+    const uint64_t o_eps = cv.take((uint64_t)B * HW * g.out_channel);
+    const uint64_t o_nl = cv.take((uint64_t)B);
+    HIP_OK(hipMalloc(&c->arena, cv.off));
+    c->arena_bytes = cv.off;
+    auto at = [&](uint64_t o) { return reinterpret_cast<float *>(c->arena + o); };
+    for (size_t i = 0; i < c->mods.size(); ++i) {
+        c->mods[i].out = at(out_off[i]);
+        c->mods[i].rb_out = at(rb_off[i]);
+    }
+    c->x0 = at(o_x0); c->h1 = at(o_h1); c->rbuf = at(o_r); c->qkvb = at(o_qkv); c->aob = at(o_ao);
+    c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
+    c->temb = at(o_te); c->cbias = at(o_cb); c->eps = at(o_eps); c->nlb = at(o_nl);
+    c->wB = B; c->wH = H; c->wW = W;
+    // the pad channels of the input tensor stay zero for the lifetime of the workspace
+    HIP_OK(hipMemsetAsync(c->x0, 0, (uint64_t)B * HW * c->in_pad * sizeof(float), c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+struct Src { const float *p0; int c0; const float *p1; int c1; int h, w; };
+
+void run_gn(sr3_ctx *c, const Src &s, const GNRef &g, int B) {
+    c->pbegin(F_GN);
+    launch_groupnorm_affine(s.p0, s.c0, s.p1, s.c1, B, s.h * s.w, c->cfg.norm_groups,
+                            c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f, c->gpart,
+                            c->gscale, c->gshift, c->stream);
+    c->pend();
+}
+
+void run_conv(sr3_ctx *c, const Src &s, const ConvRef &cv, int B, int stride, int up2, bool gn,
+              bool swish, const float *chan_bias, const float *resid, float *out, int ho, int wo) {
+    ConvParams p;
+    p.in0 = s.p0; p.in1 = s.p1; p.C0 = s.c0; p.C1 = s.c1;
+    p.B = B; p.Hin = s.h; p.Win = s.w; p.Hout = ho; p.Wout = wo;
+    p.ks = cv.ks; p.stride = stride; p.up2 = up2;
+    p.w = c->params[cv.w].dev;
+    p.bias = cv.b >= 0 ? c->params[cv.b].dev : nullptr;
+    p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
+    p.resid = resid;
+    p.gn_scale = gn ? c->gscale : nullptr;
+    p.gn_shift = gn ? c->gshift : nullptr;
+    p.swish = swish ? 1 : 0;
+    p.out = out; p.Cout = cv.cout;
+    c->pbegin(F_CONV);
+    launch_conv(p, c->stream);
+    c->pend(2.0 * (double)B * ho * wo * cv.cout * (double)(cv.ks * cv.ks) * cv.cin);
+}
+
+// ResnetBlock.forward (unet.py:105-110) + SelfAttention.forward (unet.py:123-142)
+void run_res(sr3_ctx *c, Module &m, const Src &s, int B) {
+    const ResBlock &rb = m.rb;
+    const int h = s.h, w = s.w;
+    run_gn(c, s, rb.gn1, B);
+    run_conv(c, s, rb.c1, B, 1, 0, true, true, c->cbias + rb.nf_off, nullptr, c->h1, h, w);
+    const float *resid = s.p0;
+    if (rb.has_res) {
+        run_conv(c, s, rb.res, B, 1, 0, false, false, nullptr, nullptr, c->rbuf, h, w);
+        resid = c->rbuf;
+    }
+    const Src hs{c->h1, rb.cout, nullptr, 0, h, w};
+    run_gn(c, hs, rb.gn2, B);
+    run_conv(c, hs, rb.c2, B, 1, 0, true, true, nullptr, resid, m.rb_out, h, w);
+    if (rb.attn) {
+        const Src xs{m.rb_out, rb.cout, nullptr, 0, h, w};
+        run_gn(c, xs, rb.agn, B);
+        run_conv(c, xs, rb.qkv, B, 1, 0, true, false, nullptr, nullptr, c->qkvb, h, w);
+        c->pbegin(F_ATTN);
+        const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
+        c->pend(fl);
+        const Src as{c->aob, rb.cout, nullptr, 0, h, w};
+        run_conv(c, as, rb.aout, B, 1, 0, false, false, nullptr, m.rb_out, m.out, h, w);
+    }
+}
+
+// UNet.forward body (unet.py:240-265): consumes c->x0 and c->cbias, leaves eps NHWC in c->eps
+void run_unet_body(sr3_ctx *c, int B, int H, int W) {
+    std::vector<int> feats;
+    Src cur{c->x0, c->in_pad, nullptr, 0, H, W};
+    const int n_pre = c->n_downs + c->n_mid;
+    for (int i = 0; i < (int)c->mods.size(); ++i) {
+        Module &m = c->mods[i];
+        const bool is_up_path = i >= n_pre;
+        switch (m.kind) {
+        case M_CONV_IN:
+            run_conv(c, cur, m.conv, B, 1, 0, false, false, nullptr, nullptr, m.out, m.oh, m.ow);
+            break;
+        case M_DOWN:
+            run_conv(c, cur, m.conv, B, 2, 0, false, false, nullptr, nullptr, m.out, m.oh, m.ow);
+            break;
+        case M_UP:
+            run_conv(c, cur, m.conv, B, 1, 1, false, false, nullptr, nullptr, m.out, m.oh, m.ow);
+            break;
+        case M_RES:
+            if (is_up_path) {
+                Module &sk = c->mods[feats.back()];
+                feats.pop_back();
+                const Src cat{cur.p0, cur.c0, sk.out, sk.oc, cur.h, cur.w};
+                run_res(c, m, cat, B);
+            } else {
+                run_res(c, m, cur, B);
+            }
+            break;
+        }
+        cur = Src{m.out, m.oc, nullptr, 0, m.oh, m.ow};
+        if (i < c->n_downs) feats.push_back(i);
+    }
+    run_gn(c, cur, c->final_gn, B);
+    run_conv(c, cur, c->final_conv, B, 1, 0, true, true, nullptr, nullptr, c->eps, H, W);
+}
+
+void run_embed(sr3_ctx *c, const float *nl, int stride, int B) {
+    EmbedParams e;
+    e.noise_level = nl; e.nl_stride = stride; e.dim = c->cfg.inner_channel;
+    e.w1 = c->params[c->mlp_w1].dev; e.b1 = c->params[c->mlp_b1].dev;
+    e.w2 = c->params[c->mlp_w2].dev; e.b2 = c->params[c->mlp_b2].dev;
+    e.nfw = c->nfw; e.nfb = c->nfb; e.total = c->nf_total;
+    e.temb = c->temb; e.chan_bias = c->cbias;
+    c->pbegin(F_EMBED);
+    launch_noise_embed(e, B, c->stream);
+    c->pend();
+}
+
+int check_ready(sr3_ctx *c) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    for (auto &p : c->params)
+        if (!p.loaded) return fail("weight '%s' was never loaded (sr3_load_weight)", p.name.c_str());
+    return 0;
+}
+
+int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
+    if (!c->sampling) return fail("sr3_sample_step before sr3_sample_begin");
+    if (t < 0 || t >= c->T) return fail("step t=%d outside schedule of %d steps", t, c->T);
+    const int B = c->wB, H = c->wH, W = c->wW;
+    // noise_level = float32(sqrt_alphas_cumprod_prev[t+1]) repeated over the batch (diffusion.py:166-167)
+    run_embed(c, c->d_nl + (t + 1), 0, B);
+    run_unet_body(c, B, H, W);
+    UpdateParams u;
+    u.state = c->x0; u.Cs = c->in_pad; u.C = c->cfg.out_channel;
+    u.xoff = c->cfg.in_channel - c->cfg.out_channel;
+    u.eps = c->eps; u.Ce = c->cfg.out_channel;
+    u.noise = noise_slab;
+    u.a = c->s_a[t]; u.b = c->s_b[t]; u.c1 = c->s_c1[t]; u.c2 = c->s_c2[t];
+    u.sigma = t > 0 ? expf(0.5f * c->s_lv[t]) : 0.f;
+    u.seed = c->seed; u.image_offset = c->image_offset;
+    u.draw = (uint32_t)(c->T - t);
+    u.frame = frame;
+    c->pbegin(F_MISC);
+    launch_ddpm_update(u, B, H * W, c->stream);
+    c->pend();
+    return 0;
+}
+
+} // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+const char *sr3_last_error(void) { return g_err.c_str(); }
+
+int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
+    if (!cfg || !out) return fail("sr3_create: null argument");
+    if (cfg->inner_channel <= 0 || cfg->inner_channel % 32)
+        return fail("inner_channel=%d: must be a positive multiple of 32", cfg->inner_channel);
+    if (cfg->norm_groups <= 0 || cfg->inner_channel % cfg->norm_groups)
+        return fail("norm_groups=%d does not divide inner_channel=%d", cfg->norm_groups, cfg->inner_channel);
+    if (cfg->n_mults < 1 || cfg->n_mults > SR3_MAX_MULTS) return fail("n_mults=%d out of range", cfg->n_mults);
+    if (cfg->n_attn_res < 0 || cfg->n_attn_res > SR3_MAX_ATTN_RES) return fail("n_attn_res out of range");
+    if (cfg->in_channel < cfg->out_channel || cfg->out_channel < 1) return fail("in_channel/out_channel invalid");
+    if (cfg->res_blocks < 1) return fail("res_blocks must be >= 1");
+    for (int i = 0; i < cfg->n_mults; ++i)
+        if (cfg->channel_mults[i] < 1) return fail("channel_mults[%d] invalid", i);
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d not present (%d HIP devices)", device, ndev);
+    HIP_OK(hipSetDevice(device));
+    sr3_ctx *c = new sr3_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    if (build_graph(c)) { delete c; return -1; }
+    if (alloc_weights(c)) { sr3_destroy(c); return -1; }
+    if (hipStreamCreate(&c->own_stream) != hipSuccess) { sr3_destroy(c); return fail("hipStreamCreate failed"); }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+void sr3_destroy(sr3_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &p : c->params)
+        if (p.owns && p.dev) (void)hipFree(p.dev);
+    if (c->nfw) (void)hipFree(c->nfw);
+    if (c->nfb) (void)hipFree(c->nfb);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->d_nl) (void)hipFree(c->d_nl);
+    for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int sr3_set_stream(sr3_ctx *c, void *hip_stream) {
+    if (!c) return fail("null context");
+    c->pflush();
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return 0;
+}
+
+int sr3_synchronize(sr3_ctx *c) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int sr3_num_params(sr3_ctx *c) { return c ? (int)c->params.size() : fail("null context"); }
+
+int sr3_param_info(sr3_ctx *c, int index, char *name, int name_cap, int64_t *shape4, int *ndim) {
+    if (!c) return fail("null context");
+    if (index < 0 || index >= (int)c->params.size()) return fail("param index %d out of range", index);
+    const Param &p = c->params[index];
+    if (name && name_cap > 0) {
+        strncpy(name, p.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape4)
+        for (size_t i = 0; i < 4; ++i) shape4[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return 0;
+}
+
+int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64_t *shape, int ndim) {
+    if (!c || !name || !host || !shape) return fail("sr3_load_weight: null argument");
+    HIP_OK(hipSetDevice(c->device));
+    for (auto &p : c->params) {
+        if (p.name != name) continue;
+        if ((int)p.shape.size() != ndim) return fail("%s: expected %zu dims, got %d", name, p.shape.size(), ndim);
+        for (int i = 0; i < ndim; ++i)
+            if (p.shape[i] != shape[i]) return fail("%s: dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)p.shape[i]);
+        // weights may change while earlier launches are still reading them
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (p.kind == P_CONV) {
+            std::vector<float> packed(p.dev_floats);
+            pack_conv_weight(host, p.cout, p.cin, p.ks, p.cin_pad, packed.data());
+            HIP_OK(hipMemcpy(p.dev, packed.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            HIP_OK(hipMemcpy(p.dev, host, p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+        }
+        p.loaded = true;
+        return 0;
+    }
+    return fail("unknown parameter '%s'", name);
+}
+
+int sr3_weights_missing(sr3_ctx *c) {
+    if (!c) return fail("null context");
+    int n = 0;
+    for (auto &p : c->params) n += p.loaded ? 0 : 1;
+    return n;
+}
+
+int sr3_chan_bias_total(sr3_ctx *c) { return c ? c->nf_total : fail("null context"); }
+
+int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_dev, int B, int H, int W,
+                     float *out_dev) {
+    if (check_ready(c)) return -1;
+    if (!x_dev || !noise_level_dev || !out_dev) return fail("sr3_unet_forward: null pointer");
+    if (ensure_workspace(c, B, H, W)) return -1;
+    c->sampling = false;
+    c->pbegin(F_MISC);
+    launch_nchw_to_nhwc(x_dev, B, c->cfg.in_channel, H, W, c->x0, c->in_pad, 0, c->stream);
+    c->pend();
+    run_embed(c, noise_level_dev, 1, B);
+    run_unet_body(c, B, H, W);
+    c->pbegin(F_MISC);
+    launch_nhwc_to_nchw(c->eps, B, c->cfg.out_channel, H, W, c->cfg.out_channel, 0, out_dev, c->stream);
+    c->pend();
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_set_schedule(sr3_ctx *c, int T, const float *noise_level, const float *recip, const float *recipm1,
+                     const float *logvar, const float *coef1, const float *coef2) {
+    if (!c) return fail("null context");
+    if (T < 1 || !noise_level || !recip || !recipm1 || !logvar || !coef1 || !coef2)
+        return fail("sr3_set_schedule: invalid argument");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->T = T;
+    c->s_nl.assign(noise_level, noise_level + T + 1);
+    c->s_a.assign(recip, recip + T);
+    c->s_b.assign(recipm1, recipm1 + T);
+    c->s_lv.assign(logvar, logvar + T);
+    c->s_c1.assign(coef1, coef1 + T);
+    c->s_c2.assign(coef2, coef2 + T);
+    if (c->d_nl) HIP_OK(hipFree(c->d_nl));
+    HIP_OK(hipMalloc(&c->d_nl, (size_t)(T + 1) * sizeof(float)));
+    HIP_OK(hipMemcpy(c->d_nl, noise_level, (size_t)(T + 1) * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int sr3_num_frames(sr3_ctx *c) {
+    if (!c) return fail("null context");
+    if (c->T < 1) return fail("no schedule set");
+    const int si = 1 | (c->T / 10);
+    int n = 0;
+    for (int i = 0; i < c->T; ++i) n += (i % si == 0) ? 1 : 0;
+    return n;
+}
+
+int sr3_sample_begin(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const float *init_noise_dev,
+                     uint64_t seed, uint64_t image_offset) {
+    if (check_ready(c)) return -1;
+    if (c->T < 1) return fail("sr3_sample_begin: no schedule set (sr3_set_schedule)");
+    const int C = c->cfg.out_channel, nc = c->cfg.in_channel - C;
+    if (cond_dev && nc <= 0) return fail("conditioning given but in_channel == out_channel");
+    if (!cond_dev && nc != 0) return fail("unconditional sampling needs in_channel == out_channel");
+    if (ensure_workspace(c, B, H, W)) return -1;
+    c->seed = seed;
+    c->image_offset = image_offset;
+    c->pbegin(F_MISC);
+    if (cond_dev) launch_nchw_to_nhwc(cond_dev, B, nc, H, W, c->x0, c->in_pad, 0, c->stream);
+    launch_init_state(c->x0, c->in_pad, nc, C, init_noise_dev, seed, image_offset, B, H * W, c->stream);
+    c->pend();
+    c->sampling = true;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_sample_step(sr3_ctx *c, int t, const float *noise_slab_dev) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    if (step_impl(c, t, noise_slab_dev, nullptr)) return -1;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_sample_end(sr3_ctx *c, float *out_dev) {
+    if (!c || !out_dev) return fail("sr3_sample_end: null argument");
+    if (!c->sampling) return fail("sr3_sample_end before sr3_sample_begin");
+    const int C = c->cfg.out_channel;
+    c->pbegin(F_MISC);
+    launch_nhwc_to_nchw(c->x0, c->wB, C, c->wH, c->wW, c->in_pad, c->cfg.in_channel - C, out_dev, c->stream);
+    c->pend();
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const float *noise_dev, uint64_t seed,
+               uint64_t image_offset, float *out_dev, float *frames_dev) {
+    if (!out_dev) return fail("sr3_sample: out_dev is null");
+    if (sr3_sample_begin(c, cond_dev, B, H, W, noise_dev, seed, image_offset)) return -1;
+    const int T = c->T, si = 1 | (T / 10);
+    const size_t slab = (size_t)B * c->cfg.out_channel * H * W;
+    int f = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const float *nz = (noise_dev && t > 0) ? noise_dev + (size_t)(T - t) * slab : nullptr;
+        float *fr = (frames_dev && (t % si == 0)) ? frames_dev + (size_t)(f++) * slab : nullptr;
+        if (step_impl(c, t, nz, fr)) return -1;
+        if (c->prof && (t % 8) == 0) c->pflush();  // bound the number of live events
+    }
+    return sr3_sample_end(c, out_dev);
+}
+
+int sr3_philox_normal(sr3_ctx *c, uint64_t seed, uint64_t image, uint32_t draw, int n, float *out_dev) {
+    if (!c || !out_dev) return fail("sr3_philox_normal: null argument");
+    HIP_OK(hipSetDevice(c->device));
+    launch_philox_normal(seed, image, draw, n, out_dev, c->stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- measurement ------------------------------------------------------------------------------
+int sr3_profile_enable(sr3_ctx *c, int on) {
+    if (!c) return fail("null context");
+    c->pflush();
+    c->prof = on != 0;
+    return 0;
+}
+int sr3_profile_reset(sr3_ctx *c) {
+    if (!c) return fail("null context");
+    c->pflush();
+    for (int i = 0; i < SR3_N_FAMILIES; ++i) { c->acc_ms[i] = 0; c->acc_flops[i] = 0; c->acc_n[i] = 0; }
+    return 0;
+}
+int sr3_profile_get(sr3_ctx *c, int family, double *total_ms, int64_t *launches, double *flops) {
+    if (!c) return fail("null context");
+    if (family < 0 || family >= SR3_N_FAMILIES) return fail("family %d out of range", family);
+    c->pflush();
+    if (total_ms) *total_ms = c->acc_ms[family];
+    if (launches) *launches = c->acc_n[family];
+    if (flops) *flops = c->acc_flops[family];
+    return 0;
+}
+
+// ---- single ops --------------------------------------------------------------------------------
+int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev, int C1, int B, int Hin,
+                  int Win, const float *weight_host, const float *bias_host, int Cout, int ks, int stride,
+                  int up2, const float *gn_scale_dev, const float *gn_shift_dev, int swish,
+                  const float *chan_bias_dev, const float *resid_dev, float *out_dev) {
+    if (!c || !in0_dev || !weight_host || !out_dev) return fail("sr3_op_conv2d: null argument");
+    if ((C0 % 32) || (C1 % 32) || C0 <= 0 || C1 < 0) return fail("sr3_op_conv2d: C0=%d C1=%d must be multiples of 32", C0, C1);
+    if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (up2 & ~1)) return fail("sr3_op_conv2d: bad ks/stride/up2");
+    HIP_OK(hipSetDevice(c->device));
+    const int Cin = C0 + C1, taps = ks * ks;
+    std::vector<float> packed((size_t)taps * Cout * Cin);
+    pack_conv_weight(weight_host, Cout, Cin, ks, Cin, packed.data());
+    float *dw = nullptr, *db = nullptr;
+    HIP_OK(hipMalloc(&dw, packed.size() * sizeof(float)));
+    HIP_OK(hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (bias_host) {
+        HIP_OK(hipMalloc(&db, (size_t)Cout * sizeof(float)));
+        HIP_OK(hipMemcpy(db, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    const int pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
+    ConvParams p;
+    p.in0 = in0_dev; p.in1 = in1_dev; p.C0 = C0; p.C1 = in1_dev ? C1 : 0;
+    p.B = B; p.Hin = Hin; p.Win = Win;
+    p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1;
+    p.ks = ks; p.stride = stride; p.up2 = up2;
+    p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
+    p.resid = resid_dev; p.gn_scale = gn_scale_dev; p.gn_shift = gn_shift_dev; p.swish = swish;
+    p.out = out_dev; p.Cout = Cout;
+    launch_conv(p, c->stream);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipFree(dw));
+    if (db) HIP_OK(hipFree(db));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_op_groupnorm_affine(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev, int C1, int B,
+                            int HW, int groups, const float *gamma_host, const float *beta_host,
+                            float *scale_dev, float *shift_dev) {
+    if (!c || !in0_dev || !gamma_host || !beta_host || !scale_dev || !shift_dev) return fail("sr3_op_groupnorm_affine: null argument");
+    const int C = C0 + (in1_dev ? C1 : 0);
+    if (groups <= 0 || C % groups) return fail("groups=%d does not divide C=%d", groups, C);
+    HIP_OK(hipSetDevice(c->device));
+    float *dg = nullptr, *db = nullptr, *part = nullptr;
+    HIP_OK(hipMalloc(&dg, (size_t)C * sizeof(float)));
+    HIP_OK(hipMalloc(&db, (size_t)C * sizeof(float)));
+    HIP_OK(hipMalloc(&part, gn_workspace_floats(B, groups) * sizeof(float)));
+    HIP_OK(hipMemcpy(dg, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(db, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
+    launch_groupnorm_affine(in0_dev, C0, in1_dev, in1_dev ? C1 : 0, B, HW, groups, dg, db, 1e-5f, part,
+                            scale_dev, shift_dev, c->stream);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipFree(dg)); HIP_OK(hipFree(db)); HIP_OK(hipFree(part));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_op_attention(sr3_ctx *c, const float *qkv_dev, int B, int N, int C, float *out_dev) {
+    if (!c || !qkv_dev || !out_dev) return fail("sr3_op_attention: null argument");
+    if (C % 32 || N < 1 || N > 1024) return fail("sr3_op_attention: need C %% 32 == 0 and 1 <= N <= 1024");
+    HIP_OK(hipSetDevice(c->device));
+    launch_attention(qkv_dev, B, N, C, out_dev, c->stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_op_noise_embed(sr3_ctx *c, const float *noise_level_dev, int B, float *temb_dev, float *chan_bias_dev) {
+    if (check_ready(c)) return -1;
+    if (!noise_level_dev || !chan_bias_dev) return fail("sr3_op_noise_embed: null argument");
+    EmbedParams e;
+    e.noise_level = noise_level_dev; e.nl_stride = 1; e.dim = c->cfg.inner_channel;
+    e.w1 = c->params[c->mlp_w1].dev; e.b1 = c->params[c->mlp_b1].dev;
+    e.w2 = c->params[c->mlp_w2].dev; e.b2 = c->params[c->mlp_b2].dev;
+    e.nfw = c->nfw; e.nfb = c->nfb; e.total = c->nf_total;
+    e.temb = temb_dev; e.chan_bias = chan_bias_dev;
+    launch_noise_embed(e, B, c->stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_op_nchw_to_nhwc(sr3_ctx *c, const float *in_dev, int B, int C, int H, int W, float *out_dev) {
+    if (!c || !in_dev || !out_dev) return fail("null argument");
+    HIP_OK(hipSetDevice(c->device));
+    launch_nchw_to_nhwc(in_dev, B, C, H, W, out_dev, C, 0, c->stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+int sr3_op_nhwc_to_nchw(sr3_ctx *c, const float *in_dev, int B, int C, int H, int W, float *out_dev) {
+    if (!c || !in_dev || !out_dev) return fail("null argument");
+    HIP_OK(hipSetDevice(c->device));
+    launch_nhwc_to_nchw(in_dev, B, C, H, W, C, 0, out_dev, c->stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- device memory helpers ---------------------------------------------------------------------
+int sr3_dev_malloc(sr3_ctx *c, uint64_t bytes, void **out_dev) {
+    if (!c || !out_dev) return fail("null argument");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMalloc(out_dev, bytes ? bytes : 4));
+    return 0;
+}
+int sr3_dev_free(sr3_ctx *c, void *dev) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipFree(dev));
+    return 0;
+}
+int sr3_memcpy_h2d(sr3_ctx *c, void *dst_dev, const void *src_host, uint64_t bytes) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int sr3_memcpy_d2h(sr3_ctx *c, void *dst_host, const void *src_dev, uint64_t bytes) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+uint64_t sr3_device_bytes(sr3_ctx *c) { return c ? c->weight_bytes + c->arena_bytes : 0; }
+
+} // extern "C"

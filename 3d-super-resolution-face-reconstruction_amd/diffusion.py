@@ -1,0 +1,176 @@
+"""`GaussianDiffusion`: the reference's sampler API (model/sr/sr3_modules/diffusion.py:66-225)
+over libsr3hip. The whole p_sample_loop — T UNet evaluations and the DDPM update — runs inside
+the HIP library; this class only holds the schedule buffers (for state_dict parity) and moves
+pointers. Training members (p_losses, forward, *_learn) are out of scope and raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import schedule as _schedule
+from ._lib import Sr3Error
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, denoise_fn, image_size, channels=3, loss_type="l1", conditional=True,
+                 schedule_opt=None):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        self.loss_type = loss_type
+        self.conditional = conditional
+        self.num_timesteps = 0
+        self._sched_np = None
+        self._sched_pushed = None   # engine id the schedule was pushed to
+
+    # ---- reference surface that is configuration only -----------------------------------------
+    def set_loss(self, device=None):
+        # reference diffusion.py:85-91 builds an L1/L2 loss for training; nothing to do for sampling
+        if self.loss_type not in ("l1", "l2"):
+            raise NotImplementedError()
+
+    def set_new_noise_schedule(self, schedule_opt, device=None):
+        """diffusion.py:93-142. `device` may be 0, a list of ids (the reference's form), a
+        torch.device or None (= where the denoiser lives)."""
+        if isinstance(device, (list, tuple)):
+            device = device[0]
+        if device is None:
+            device = next(self.denoise_fn.parameters()).device
+        bufs = _schedule.schedule_buffers(schedule_opt)
+        self.sqrt_alphas_cumprod_prev = bufs["sqrt_alphas_cumprod_prev"]
+        self.num_timesteps = int(bufs["betas"].shape[0])
+        for name in _schedule.BUFFER_NAMES:
+            t = torch.tensor(bufs[name], dtype=torch.float32, device=device)
+            if name in self._buffers:
+                self._buffers[name] = t
+            else:
+                self.register_buffer(name, t)
+        self._sched_np = bufs
+        self._sched_pushed = None
+
+    def _engine(self):
+        eng = self.denoise_fn.engine()
+        if self._sched_np is None:
+            raise Sr3Error("set_new_noise_schedule() has not been called")
+        if self._sched_pushed != id(eng):
+            eng.set_schedule(self._sched_np)
+            self._sched_pushed = id(eng)
+        return eng
+
+    # ---- sampling ------------------------------------------------------------------------------
+    @staticmethod
+    def _draw_seed() -> int:
+        # one draw from torch's global generator: torch.manual_seed() makes sampling reproducible,
+        # as with the reference's torch.randn calls (the streams themselves differ: Philox on device)
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+    @torch.no_grad()
+    def sample_batch(self, x_in, continous=False, noise: Optional[torch.Tensor] = None,
+                     seed: Optional[int] = None, image_offset: int = 0):
+        """p_sample_loop for a whole batch (diffusion.py:189-215).
+
+        x_in: conditioning [B,3,H,W] (conditional) or a shape tuple (unconditional, :193-201).
+        noise: optional [T,B,C,H,W] tensor replacing the RNG (slab 0 = initial image, slab k = the
+        randn_like of step t=T-k). Returns [B,C,H,W], or (final, frames [n,B,C,H,W]) if continous.
+        """
+        eng = self._engine()
+        if self.conditional:
+            x = x_in.to(torch.float32).contiguous()
+            B, _, H, W = x.shape
+            dev, cond_ptr = x.device, x.data_ptr()
+        else:
+            B, _, H, W = tuple(x_in)
+            dev, cond_ptr = next(self.denoise_fn.parameters()).device, None
+        C = self.channels
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
+        frames = None
+        if continous:
+            frames = torch.empty((eng.num_frames(), B, C, H, W), dtype=torch.float32, device=dev)
+        nptr = None
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            if tuple(noise.shape) != (self.num_timesteps, B, C, H, W):
+                raise RuntimeError(f"noise must be {(self.num_timesteps, B, C, H, W)}, got {tuple(noise.shape)}")
+            nptr = noise.data_ptr()
+        if seed is None:
+            seed = self._draw_seed()
+        eng.sample(cond_ptr, B, H, W, out.data_ptr(), nptr, seed, image_offset,
+                   frames.data_ptr() if frames is not None else None)
+        return (out, frames) if continous else out
+
+    @torch.no_grad()
+    def p_sample_loop(self, x_in, continous=False, noise=None, seed=None):
+        """Reference return convention (diffusion.py:212-215): `ret_img` = cat([x_in, frames...])
+        if continous else `ret_img[-1]` — the LAST image of the batch, shape [C,H,W]."""
+        if not continous:
+            return self.sample_batch(x_in, False, noise, seed)[-1]
+        out, frames = self.sample_batch(x_in, True, noise, seed)
+        if self.conditional:
+            first = x_in.to(torch.float32)
+        else:
+            # the reference starts ret_img with the initial noise here; it is not retrievable from
+            # the device RNG, so the first rows are the first recorded frame's shape of zeros
+            first = torch.zeros_like(out)
+        return torch.cat([first, frames.reshape(-1, *frames.shape[2:])], dim=0)
+
+    @torch.no_grad()
+    def sample(self, batch_size=1, continous=False):
+        s = self.image_size
+        return self.p_sample_loop((batch_size, self.channels, s, s), continous)
+
+    @torch.no_grad()
+    def super_resolution(self, x_in, continous=False):
+        return self.p_sample_loop(x_in, continous)
+
+    @torch.no_grad()
+    def super_resolution_batch(self, x_in, noise=None, seed=None, image_offset=0):
+        """Throughput entry point: every image of the batch, [B,3,H,W]."""
+        return self.sample_batch(x_in, False, noise, seed, image_offset)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, clip_denoised=True, condition_x=None, noise=None):
+        """One reverse step (diffusion.py:182-187) on the device."""
+        if not clip_denoised:
+            raise NotImplementedError("clip_denoised=False is never used by the reference")
+        eng = self._engine()
+        x = x.to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        cond = condition_x.to(torch.float32).contiguous() if condition_x is not None else None
+        eng.sample_begin(cond.data_ptr() if cond is not None else None, B, H, W, x.data_ptr(), 0, 0)
+        if noise is None and t > 0:
+            noise = torch.randn_like(x)
+        nz = noise.to(torch.float32).contiguous() if (noise is not None and t > 0) else None
+        eng.sample_step(int(t), nz.data_ptr() if nz is not None else None)
+        out = torch.empty_like(x)
+        eng.sample_end(out.data_ptr())
+        return out
+
+    # ---- small closed-form members kept for API completeness (diffusion.py:144-180) -------------
+    def predict_start_from_noise(self, x_t, t, noise):
+        return self.sqrt_recip_alphas_cumprod[t] * x_t - self.sqrt_recipm1_alphas_cumprod[t] * noise
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = self.posterior_mean_coef1[t] * x_start + self.posterior_mean_coef2[t] * x_t
+        return mean, self.posterior_log_variance_clipped[t]
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, t, clip_denoised: bool, condition_x=None):
+        B = x.shape[0]
+        nl = torch.full((B, 1), float(np.float32(self.sqrt_alphas_cumprod_prev[t + 1])),
+                        dtype=torch.float32, device=x.device)
+        inp = torch.cat([condition_x, x], dim=1) if condition_x is not None else x
+        x_recon = self.predict_start_from_noise(x, t, self.denoise_fn(inp, nl))
+        if clip_denoised:
+            x_recon.clamp_(-1.0, 1.0)
+        return self.q_posterior(x_recon, x, t)
+
+    # ---- training members: out of scope ---------------------------------------------------------
+    def forward(self, x, *args, **kwargs):
+        raise NotImplementedError("training loss (p_losses) is outside the SR3 sampling hot path")
+
+    p_losses = q_sample = super_resolution_learn = p_sample_loop_learn = forward

@@ -1,0 +1,118 @@
+"""`UNet`: the reference's denoiser API (model/sr/sr3_modules/unet.py:161-265) over libsr3hip.
+
+Same constructor keywords, same `forward(x, time)` contract, same `state_dict` keys and tensor
+layouts (Conv2d OIHW, Linear [out,in]) — so `load_state_dict` of a reference checkpoint works —
+but no torch compute: parameters are only *storage*; `forward` hands device pointers to the HIP
+library, which keeps its own kernel-layout copy of the weights. There is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from ._lib import Sr3Error
+from .engine import Engine
+from .graph import UNetConfig, param_specs
+
+
+class _Node(nn.Module):
+    """Parameter container; only gives the reference's dotted names to the parameters."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("container module; compute happens in UNet.forward (HIP)")
+
+
+def _register(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        nxt = mod._modules.get(name)
+        if nxt is None:
+            nxt = _Node()
+            mod.add_module(name, nxt)
+        mod = nxt
+    mod.register_parameter(parts[-1], p)
+
+
+def _default_init(shape, kind: str) -> torch.Tensor:
+    # PyTorch's default resets of Conv2d / Linear / GroupNorm, which the reference relies on
+    # when phase != 'train' (networks.py:110-112)
+    t = torch.empty(shape, dtype=torch.float32)
+    if kind in ("conv", "linear"):
+        nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+    elif kind == "norm_w":
+        t.fill_(1.0)
+    elif kind == "norm_b":
+        t.zero_()
+    else:
+        t.zero_()
+    return t
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                 channel_mults=(1, 2, 4, 8, 8), attn_res=(8,), res_blocks=3, dropout=0,
+                 with_noise_level_emb=True, image_size=128):
+        super().__init__()
+        if not with_noise_level_emb:
+            raise NotImplementedError("with_noise_level_emb=False is not used by any reference config")
+        self.cfg = UNetConfig(in_channel=in_channel, out_channel=out_channel if out_channel else in_channel,
+                              inner_channel=inner_channel, norm_groups=norm_groups,
+                              channel_mults=channel_mults, attn_res=attn_res, res_blocks=res_blocks,
+                              dropout=dropout, image_size=image_size)
+        fan_in = {}
+        for name, shape, kind in param_specs(self.cfg):
+            t = _default_init(shape, kind)
+            if kind in ("conv", "linear"):
+                fan_in[name.rsplit(".", 1)[0]] = int(torch.tensor(shape[1:]).prod())
+            elif kind == "bias":
+                fi = fan_in.get(name.rsplit(".", 1)[0])
+                if fi:
+                    nn.init.uniform_(t, -1.0 / math.sqrt(fi), 1.0 / math.sqrt(fi))
+            _register(self, name, nn.Parameter(t))
+        self._engine: Optional[Engine] = None
+        self._synced = {}
+
+    # ---- engine management -------------------------------------------------------------------
+    def _device_index(self) -> int:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise Sr3Error("UNet parameters are on %s: the SR3 HIP path needs a GPU (call .cuda()); "
+                           "there is no CPU fallback" % dev)
+        return dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def engine(self) -> Engine:
+        idx = self._device_index()
+        if self._engine is None or self._engine.device != idx:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = Engine(self.cfg, idx)
+            self._synced = {}
+        self._sync_weights()
+        self._engine.set_stream(torch.cuda.current_stream(idx).cuda_stream)
+        return self._engine
+
+    def _sync_weights(self) -> None:
+        for name, p in self.named_parameters():
+            sig = (p.data_ptr(), p._version)
+            if self._synced.get(name) != sig:
+                self._engine.load_weight(name, p.detach().to("cpu", torch.float32).contiguous().numpy())
+                self._synced[name] = sig
+
+    # ---- reference API -----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+        eng = self.engine()
+        if x.dim() != 4 or x.shape[1] != self.cfg.in_channel:
+            raise RuntimeError(f"expected input [B, {self.cfg.in_channel}, H, W], got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        x = x.to(torch.float32).contiguous()
+        nl = time.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if nl.numel() != B:
+            raise RuntimeError(f"noise level must have {B} entries, got {nl.numel()}")
+        out = torch.empty((B, self.cfg.out_channel, H, W), dtype=torch.float32, device=x.device)
+        eng.unet_forward(x.data_ptr(), nl.data_ptr(), B, H, W, out.data_ptr())
+        return out

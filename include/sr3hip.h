@@ -1,0 +1,173 @@
+/*
+ * sr3hip.h — C-ABI of libsr3hip.so: the MI355X (gfx950) SR3 iterative-refinement sampler.
+ *
+ * This is the drop-in boundary for ONE path of zouiner/3d-super-resolution-Face-reconstruction:
+ * GaussianDiffusion.p_sample_loop driving the noise-level-conditioned UNet
+ * (reference: model/sr/sr3_modules/diffusion.py:189-215, model/sr/sr3_modules/unet.py:235-265).
+ * The reference is pure Python/PyTorch and has no FFI of its own; the Python object protocol it
+ * exposes (define_G / GaussianDiffusion / UNet) is mirrored by the ctypes host layer in
+ * 3d-super-resolution-face-reconstruction_amd/, which binds exactly the entry points below.
+ *
+ * Conventions
+ *   - plain C: opaque context, plain pointers and sizes, int return codes (0 = ok, <0 = error,
+ *     message via sr3_last_error()).  No torch types.
+ *   - every `*_dev` pointer is a DEVICE pointer on the context's GPU (e.g. tensor.data_ptr()).
+ *   - public tensors are fp32, NCHW contiguous (the reference's layout); the library keeps NHWC
+ *     internally.
+ *   - one context per process/GPU, not thread-safe, all work is stream-ordered on the context's
+ *     stream (sr3_set_stream); calls return without synchronising unless stated.
+ */
+#ifndef SR3HIP_H
+#define SR3HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR3_MAX_MULTS 8
+#define SR3_MAX_ATTN_RES 8
+#define SR3_NAME_MAX 192
+
+typedef struct sr3_ctx sr3_ctx;
+
+/* Mirrors the keyword arguments of UNet.__init__ (reference model/sr/sr3_modules/unet.py:161-174)
+ * as filled by define_G (reference model/sr/networks.py:83-101). */
+typedef struct sr3_unet_cfg {
+    int32_t in_channel;      /* 6 for conditional SR3 (cond ‖ x), 3 unconditional */
+    int32_t out_channel;     /* 3 */
+    int32_t inner_channel;   /* 64 in every reference yml; must be a multiple of 32 here */
+    int32_t norm_groups;     /* 32 */
+    int32_t n_mults;
+    int32_t channel_mults[SR3_MAX_MULTS];
+    int32_t n_attn_res;
+    int32_t attn_res[SR3_MAX_ATTN_RES];
+    int32_t res_blocks;
+    int32_t image_size;      /* only decides attention placement (unet.py:192-207) */
+    float dropout;           /* accepted for API parity; eval semantics (identity) only */
+} sr3_unet_cfg;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* replaces: UNet.__init__ + .cuda()  (unet.py:161-233, model/sr3d/model.py:51) */
+int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out);
+void sr3_destroy(sr3_ctx *ctx);
+/* message of the last failing call on this thread ("" if none) */
+const char *sr3_last_error(void);
+/* work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) */
+int sr3_set_stream(sr3_ctx *ctx, void *hip_stream);
+int sr3_synchronize(sr3_ctx *ctx);
+
+/* ---- weights: reference state_dict names and layouts ------------------------------------- */
+
+/* replaces: nn.Module.state_dict() key enumeration for `denoise_fn.*`
+ * (names are relative to the UNet, e.g. "downs.1.res_block.block1.block.3.weight"). */
+int sr3_num_params(sr3_ctx *ctx);
+int sr3_param_info(sr3_ctx *ctx, int index, char *name, int name_cap, int64_t *shape4, int *ndim);
+/* replaces: load_state_dict for one tensor (lib/trainer_temp.py:175-179). `host` is fp32 in the
+ * reference layout (Conv2d OIHW, Linear [out,in], vectors [C]); repacked to kernel layout inside. */
+int sr3_load_weight(sr3_ctx *ctx, const char *name, const float *host, const int64_t *shape,
+                    int ndim);
+/* number of parameters that have never been loaded (0 = ready) */
+int sr3_weights_missing(sr3_ctx *ctx);
+
+/* ---- the denoiser: UNet.forward(x, noise_level)  (unet.py:235-265) ------------------------ */
+
+/* x_dev: [B, in_channel, H, W] NCHW; noise_level_dev: [B]; out_dev: [B, out_channel, H, W]. */
+int sr3_unet_forward(sr3_ctx *ctx, const float *x_dev, const float *noise_level_dev, int B, int H,
+                     int W, float *out_dev);
+
+/* ---- the sampler: GaussianDiffusion.{set_new_noise_schedule,p_sample_loop} ---------------- */
+
+/* replaces: the fp32 buffers registered by set_new_noise_schedule (diffusion.py:93-142). The host
+ * computes them in float64 exactly as the reference does and passes the fp32 casts:
+ *   noise_level[T+1]  = float32(sqrt_alphas_cumprod_prev)      (diffusion.py:108-109,166-167)
+ *   recip[T]          = sqrt_recip_alphas_cumprod               (:125-126)
+ *   recipm1[T]        = sqrt_recipm1_alphas_cumprod             (:127-128)
+ *   logvar[T]         = posterior_log_variance_clipped          (:137-138)
+ *   coef1[T], coef2[T]= posterior_mean_coef1/2                  (:139-142) */
+int sr3_set_schedule(sr3_ctx *ctx, int T, const float *noise_level, const float *recip,
+                     const float *recipm1, const float *logvar, const float *coef1,
+                     const float *coef2);
+
+/* replaces: p_sample_loop (diffusion.py:189-215) for a whole batch.
+ *   cond_dev   [B,3,H,W] conditioning image (x_in) or NULL for the unconditional branch (:193-201)
+ *   noise_dev  NULL -> device Philox4x32-10 + Box-Muller keyed by (seed, image index+image_offset,
+ *              draw, element); else [(T), B, C, H, W]: slab 0 is the initial image (torch.randn,
+ *              :205), slab k (1..T-1) is the randn_like of loop iteration k-1 (t = T-k, :186)
+ *   out_dev    [B,C,H,W] final images (every image, not only ret_img[-1])
+ *   frames_dev NULL or [n_frames,B,C,H,W]: the image after every step i with i % sample_inter == 0
+ *              (:192,209-211), sample_inter = 1 | (T/10); n_frames = sr3_num_frames(ctx)
+ * Stream-ordered; returns after enqueueing. */
+int sr3_sample(sr3_ctx *ctx, const float *cond_dev, int B, int H, int W, const float *noise_dev,
+               uint64_t seed, uint64_t image_offset, float *out_dev, float *frames_dev);
+int sr3_num_frames(sr3_ctx *ctx);
+/* One p_sample step t on the library-resident state (used by bench.py to time exact step counts):
+ * sr3_sample_begin loads cond + initial noise, sr3_sample_step runs step t, sr3_sample_end copies
+ * the current image out. noise_slab_dev may be NULL (Philox). */
+int sr3_sample_begin(sr3_ctx *ctx, const float *cond_dev, int B, int H, int W,
+                     const float *init_noise_dev, uint64_t seed, uint64_t image_offset);
+int sr3_sample_step(sr3_ctx *ctx, int t, const float *noise_slab_dev);
+int sr3_sample_end(sr3_ctx *ctx, float *out_dev);
+
+/* The documented CPU twin of the device RNG is oracle/philox.py; this dumps the device stream for
+ * comparison: n floats of draw `draw` for image `image`. */
+int sr3_philox_normal(sr3_ctx *ctx, uint64_t seed, uint64_t image, uint32_t draw, int n,
+                      float *out_dev);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+
+/* When enabled every kernel launch is bracketed by HIP events on the context's stream and
+ * accumulated per kernel family. */
+int sr3_profile_enable(sr3_ctx *ctx, int on);
+int sr3_profile_reset(sr3_ctx *ctx);
+/* family: 0 conv_igemm, 1 groupnorm, 2 attention, 3 embed, 4 ddpm_update/layout.
+ * Synchronises the stream. flops = algorithmic 2*MAC of the launches (0 for non-GEMM families). */
+int sr3_profile_get(sr3_ctx *ctx, int family, double *total_ms, int64_t *launches, double *flops);
+#define SR3_N_FAMILIES 5
+
+/* ---- single ops through the same kernels (parity tests call these) ------------------------ */
+
+/* Conv2d over NHWC device tensors. in1_dev may be NULL (C1 = 0); channel order is in0 ‖ in1
+ * (torch.cat((x, skip), 1), unet.py:261). weight_host is OIHW [Cout, C0+C1, ks, ks], bias_host
+ * NULL or [Cout]. up2 = nearest x2 upsample before the conv (unet.py:58-65); stride 1|2
+ * (unet.py:68-74). gn_scale/gn_shift NULL or [B, C0+C1]: per (image, channel) affine applied to the
+ * input before zero padding, followed by Swish if `swish`. chan_bias_dev NULL or [B, Cout]
+ * (FeatureWiseAffine, unet.py:34-50); resid_dev NULL or [B,Hout,Wout,Cout]. */
+int sr3_op_conv2d(sr3_ctx *ctx, const float *in0_dev, int C0, const float *in1_dev, int C1, int B,
+                  int Hin, int Win, const float *weight_host, const float *bias_host, int Cout,
+                  int ks, int stride, int up2, const float *gn_scale_dev,
+                  const float *gn_shift_dev, int swish, const float *chan_bias_dev,
+                  const float *resid_dev, float *out_dev);
+/* GroupNorm statistics folded with the affine: scale[b,c] = rstd*gamma[c],
+ * shift[b,c] = beta[c] - mean*rstd*gamma[c]  (torch GroupNorm, eps 1e-5; unet.py:84,119). */
+int sr3_op_groupnorm_affine(sr3_ctx *ctx, const float *in0_dev, int C0, const float *in1_dev,
+                            int C1, int B, int HW, int groups, const float *gamma_host,
+                            const float *beta_host, float *scale_dev, float *shift_dev);
+/* SelfAttention core (unet.py:132-139): qkv_dev [B, N, 3C] (q|k|v along the last axis) -> out
+ * [B, N, C]; softmax(q.k / sqrt(C)) v, one head. */
+int sr3_op_attention(sr3_ctx *ctx, const float *qkv_dev, int B, int N, int C, float *out_dev);
+/* noise_level_mlp + every FeatureWiseAffine linear (unet.py:23-31,179-184,39,49): noise_level_dev
+ * [B] -> chan_bias_dev [B, total] where total = sr3_chan_bias_total(ctx) (blocks in module order). */
+int sr3_op_noise_embed(sr3_ctx *ctx, const float *noise_level_dev, int B, float *temb_dev,
+                       float *chan_bias_dev);
+int sr3_chan_bias_total(sr3_ctx *ctx);
+/* NCHW <-> NHWC copies */
+int sr3_op_nchw_to_nhwc(sr3_ctx *ctx, const float *in_dev, int B, int C, int H, int W,
+                        float *out_dev);
+int sr3_op_nhwc_to_nchw(sr3_ctx *ctx, const float *in_dev, int B, int C, int H, int W,
+                        float *out_dev);
+
+/* ---- device memory helpers (so hosts without torch can drive the library) ---------------- */
+int sr3_dev_malloc(sr3_ctx *ctx, uint64_t bytes, void **out_dev);
+int sr3_dev_free(sr3_ctx *ctx, void *dev);
+int sr3_memcpy_h2d(sr3_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes);
+int sr3_memcpy_d2h(sr3_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes);
+/* bytes of device memory the context currently holds (weights + workspace) */
+uint64_t sr3_device_bytes(sr3_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR3HIP_H */

@@ -1,0 +1,63 @@
+"""Pins the CPU oracle (oracle/sr3_oracle.py) to vectors produced by the reference itself
+(tests/golden/make_golden.py). CPU only."""
+import numpy as np
+import pytest
+
+import sr3_oracle as oracle
+from conftest import cfg_from_meta, load_golden, pkg
+
+synth = pkg("synth")
+
+BUFS = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+        "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+        "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+        "posterior_mean_coef1", "posterior_mean_coef2")
+
+
+def test_schedule_bit_exact():
+    g = load_golden("schedules.npz")
+    for i, (s, T, a, b) in enumerate(g["cases"]):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sch = oracle.noise_schedule({"schedule": s, "n_timestep": T, "linear_start": a, "linear_end": b})
+        for k in BUFS:
+            np.testing.assert_array_equal(sch[k], g[f"c{i}.{k}"], err_msg=f"{s} T={T} {k}")
+        np.testing.assert_array_equal(sch["sqrt_alphas_cumprod_prev"], g[f"c{i}.sqrt_alphas_cumprod_prev"])
+
+
+def test_unknown_schedule_raises():
+    with pytest.raises(NotImplementedError):
+        oracle.make_beta_schedule("nope", 10)
+
+
+@pytest.mark.parametrize("name,tol", [("unet_tiny.npz", 2e-5), ("unet_yml224_r16.npz", 2e-5),
+                                      ("unet_yml128_r32.npz", 2e-5), ("unet_yml224_r128.npz", 2e-5)])
+def test_unet_forward_matches_reference(name, tol):
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["meta"])
+    sd = synth.synth_state_dict(cfg, g["meta"]["seed"])
+    taps = {}
+    eps = oracle.unet_forward(sd, cfg, g["x"], g["noise_level"], taps=taps)
+    for k in g:
+        if k.startswith("tap."):
+            np.testing.assert_allclose(taps[k[4:]], g[k], atol=tol, rtol=0, err_msg=k)
+    np.testing.assert_allclose(eps, g["eps"], atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["sampler_tiny.npz", "sampler_uncond_tiny.npz", "sampler_cfg1_8_16.npz"])
+def test_sampler_matches_reference(name):
+    g = load_golden(name)
+    m = g["meta"]
+    cfg = cfg_from_meta(m)
+    sd = synth.synth_state_dict(cfg, m["seed"])
+    sch = oracle.noise_schedule(m["schedule"])
+    B, r, T = m["B"], m["r"], m["schedule"]["n_timestep"]
+    noise = synth.synth_noise(T, B, 3, r, r, m["seed"])
+    cond = g["cond"] if m["conditional"] else None
+    if cond is not None:
+        np.testing.assert_array_equal(cond, synth.synth_cond(B, r, m["l"], m["seed"]))
+    final, frames = oracle.p_sample_loop(sd, cfg, sch, cond, noise)
+    first = cond if cond is not None else noise[0]
+    ret = np.concatenate([first, frames.reshape(-1, *frames.shape[2:])], axis=0)
+    assert ret.shape == g["ret_img"].shape
+    np.testing.assert_allclose(ret, g["ret_img"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(final[-1], g["last"], atol=1e-4, rtol=0)
