@@ -24,6 +24,13 @@ class _Node(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover
         raise RuntimeError("container module; compute happens in UNet.forward (HIP)")
 
+    def __getitem__(self, idx):
+        # numeric children behave like the reference's ModuleList / Sequential entries
+        return self._modules[str(idx)]
+
+    def __len__(self):
+        return len(self._modules)
+
 
 def _register(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
     parts = dotted.split(".")

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SR images/sec for the full SR3 p_sample_loop (16->128) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE p_sample step (UNet forward + DDPM update, reference diffusion.py:182-187) over
+one batch of B images per GPU; an image needs T such steps, so
+    value [img/s] = n_gpus * B / (T * seconds_per_step).
+Every step costs the same (the step index only changes scalars), so K timed steps measure the
+loop; `--steps T` times the whole loop. Workload = BASELINE.json configs[1]:
+sr_sr3_VGGF2_16_128, batch 64 per GPU, T = 1000, yml-literal UNet (92.6 M parameters,
+89.0 GFLOP per image per step), synthetic conditioning images and synthetic weights.
+Inputs are resident in HBM before the timed region. Multi-GPU: the batch is sharded (weak
+scaling, 64 images per GPU), no collective inside the loop, one RCCL all-gather of the finished
+images at the end of the timed region.
+
+The JSON line also carries
+  roofline     the conv implicit-GEMM kernel family: algorithmic FLOPs / HIP-event time per launch
+               against the 157.3 TFLOP/s f32-input MFMA peak (exact f32 is what parity needs)
+  cpu_baseline the numpy oracle (a port of the reference's CPU path) timed on this host on a
+               bounded sample, and the GPU-vs-oracle parity of that same sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = "3d-super-resolution-face-reconstruction_amd"
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--lres", type=int, default=16)
+    ap.add_argument("--T", type=int, default=1000, help="diffusion steps per image (BASELINE configs[1]: 1000)")
+    ap.add_argument("--image-size", type=int, default=224, help="UNet image_size key: 224 = yml-literal, 128 = 6 attention modules")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
+    """Oracle (CPU port) on a bounded sample of the same workload + parity of the GPU on it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sr3_oracle as oracle      # checker / baseline only
+    metrics = importlib.import_module(PKG + ".metrics")
+    B, r, T, K = args.cpu_batch, args.res, args.T, args.cpu_steps
+    cond = synth.synth_cond(B, r, args.lres, 4242)
+    noise = synth.synth_noise(K + 1, B, 3, r, r, 4242)
+    sch = oracle.noise_schedule(sched_opt)
+    x = noise[0]
+    t0 = time.perf_counter()
+    for k in range(K):
+        x = oracle.p_sample(sd, cfg, sch, x, T - 1 - k, cond, noise[k + 1])
+    dt = time.perf_counter() - t0
+    # the same K steps on the GPU with the same injected noise
+    dc, dn, out = eng.to_device(cond), eng.to_device(noise), eng.buffer(B * 3 * r * r)
+    slab = B * 3 * r * r * 4
+    eng.sample_begin(dc.ptr, B, r, r, dn.ptr)
+    for k in range(K):
+        eng.sample_step(T - 1 - k, dn.ptr + (k + 1) * slab)
+    eng.sample_end(out.ptr)
+    got = out.download((B, 3, r, r))
+    try:
+        import threadpoolctl
+        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    base = {
+        "value": B / (T * dt / K), "unit": "img/s", "cores": int(cores), "kind": "port",
+        "sample": f"{K} p_sample steps of B={B} at {r}x{r} with the numpy oracle ({dt:.1f} s), scaled to T={T}",
+    }
+    parity = {"max_abs": float(np.abs(got - x).max()),
+              "psnr_db": metrics.batch_psnr(got, x), "steps": K, "tolerance": 1e-3}
+    return base, parity
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    distm = importlib.import_module(PKG + ".dist")
+    synth = importlib.import_module(PKG + ".synth")
+    graph = importlib.import_module(PKG + ".graph")
+    schedule = importlib.import_module(PKG + ".schedule")
+    Engine = importlib.import_module(PKG + ".engine").Engine
+
+    rank, world, local = distm.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    B, r, T, K, W = args.batch, args.res, args.T, args.steps, args.warmup
+
+    cfg = synth.yml_unet_config(args.image_size)
+    sched_opt = {"schedule": "linear", "n_timestep": T, "linear_start": 1e-6, "linear_end": 1e-2}
+    sd = synth.synth_state_dict(cfg, 2024)
+    eng = Engine(cfg, local)
+    eng.load_state_dict(sd)
+    eng.set_schedule(schedule.schedule_buffers(sched_opt))
+    stream = torch.cuda.current_stream(local)
+    eng.set_stream(stream.cuda_stream)
+
+    # inputs resident in HBM: this rank's shard of the global batch (weak scaling)
+    a, _ = distm.shard_bounds(B * world, world, rank)
+    cond = torch.from_numpy(synth.synth_cond(B, r, args.lres, 1000 + rank)).cuda()
+    out = torch.empty((B, 3, r, r), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((B * world, 3, r, r), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def run_steps(n, t_start):
+        t = t_start
+        for _ in range(n):
+            eng.sample_step(t, None)         # device Philox noise
+            t = t - 1 if t > 0 else T - 1
+        return t
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.sample_begin(cond.data_ptr(), B, r, r, None, seed=7, image_offset=a)
+    t_next = run_steps(W, T - 1)
+    barrier()
+    t0 = time.perf_counter()
+    t_next = run_steps(K, t_next)
+    eng.sample_end(out.data_ptr())
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, out)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    sec_per_step = dt / K
+
+    # ---- roofline of the dominant kernel family (rank 0): same K steps, HIP events per launch
+    roof = None
+    if rank == 0:
+        eng.profile_reset()
+        eng.profile_enable(True)
+        run_steps(K, t_next)
+        prof = eng.profile_get()
+        eng.profile_enable(False)
+        conv = prof["conv_igemm"]
+        n = max(1, conv["launches"])
+        avg_ms = conv["ms"] / n
+        achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        total_ms = sum(v["ms"] for v in prof.values())
+        roof = {
+            "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "conv_igemm_f32<BM,BN> (all tile shapes)", "launches_per_step": n / K,
+            "avg_launch_ms": avg_ms, "flop_per_launch": conv["flops"] / n,
+            "family_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
+            "whole_step_frac": (B * graph.flops_per_image(cfg, r, r) / sec_per_step / 1e12) / F32_MFMA_PEAK_TFLOPS,
+            "event_timed_step_ms": total_ms / K,
+        }
+
+    if rank == 0:
+        res = {
+            "metric": "SR images/sec (full p_sample_loop, 16->128)",
+            "value": world * B / (T * sec_per_step), "unit": "img/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": sec_per_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sr_sr3_VGGF2_{args.lres}_{r} p_sample_loop, yml UNet image_size={args.image_size}",
+                       "batch_per_gpu": B, "global_batch": B * world, "T": T,
+                       "gflop_per_image_step": graph.flops_per_image(cfg, r, r) / 1e9,
+                       "step": "one p_sample step (UNet forward + DDPM update) over the per-GPU batch",
+                       "parallelism": f"batch-sharded x{world}, one all-gather at the end"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            base, parity = cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth)
+            res["cpu_baseline"] = base
+            res["parity"] = parity
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
