@@ -18,22 +18,37 @@
 // MFMA j of group kk for both operands, so the k-permutation is consistent between A and B.
 #include "sr3_internal.h"
 #include <stdio.h>
+#include <type_traits>
 
 namespace sr3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native vector (not HIP's float4 struct: struct copies through a register array become
+// memcpys via scratch memory)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int BK = 32;          // channels per K-step
 constexpr int LDSK = BK + 4;    // padded LDS row (floats)
 
+// compile-time loop: every index is a constant in the front end, so register arrays are split
+// into scalars before any loop pass (runtime-indexed arrays end up in scratch, guide rule 20)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 __device__ __forceinline__ float swish_f(float x) {
     // x * sigmoid(x); v_exp_f32 / v_rcp_f32 are 1 ulp on gfx950
     return x * __frcp_rn(1.0f + __expf(-x));
 }
 
-template <int BM, int BN, int WGM, int WGN>
+// MODE 0: raw input, 1: per-(image, channel) affine (GroupNorm folded), 2: affine + Swish
+template <int BM, int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -93,77 +108,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
             a_ux[i] = -(1 << 20);
         }
     }
+    // weight rows are clamped (rows past Cout are never stored); per-thread element offsets
+    const float *b_ptr[BR];
+    static_for<BR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        b_ptr[i] = p.w + (size_t)min(n0 + r0 + 32 * i, p.Cout - 1) * Cin + 4 * q;
+    });
 
-    float4 ra[AR], rsc[AR], rsh[AR], rb[BR];
+    f32x4 ra[AR], rsc[AR], rsh[AR], rb[BR];
     unsigned vmask = 0;
-    const bool has_gn = p.gn_scale != nullptr;
-
-    auto issue_loads = [&](int kidx) {
-        const int cc = kidx / taps;
-        const int tap = kidx - cc * taps;
-        const int c0 = cc * BK;
-        const int dy = tap / p.ks, dx = tap - dy * p.ks;
-        const float *src;
-        int Cs, cl;
-        if (c0 < p.C0) {
-            src = p.in0; Cs = p.C0; cl = c0;
-        } else {
-            src = p.in1; Cs = p.C1; cl = c0 - p.C0;
-        }
-        vmask = 0;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int uy = a_uy[i] + dy, ux = a_ux[i] + dx;
-            const bool ok = (unsigned)uy < (unsigned)Hv && (unsigned)ux < (unsigned)Wv;
-            if (ok) {
-                const int iy = uy >> p.up2, ix = ux >> p.up2;
-                const size_t off = ((size_t)(a_n[i] * p.Hin + iy) * p.Win + ix) * Cs + cl + 4 * q;
-                ra[i] = *reinterpret_cast<const float4 *>(src + off);
-                vmask |= 1u << i;
-                if (has_gn) {
-                    const size_t go = (size_t)a_n[i] * Cin + c0 + 4 * q;
-                    rsc[i] = *reinterpret_cast<const float4 *>(p.gn_scale + go);
-                    rsh[i] = *reinterpret_cast<const float4 *>(p.gn_shift + go);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            if (n < p.Cout) {
-                rb[i] = *reinterpret_cast<const float4 *>(p.w + ((size_t)tap * p.Cout + n) * Cin + c0 + 4 * q);
-            } else {
-                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-
-    auto stage_to_lds = [&](int buf) {
-        float *Ad = As + buf * BM * LDSK;
-        float *Bd = Bs + buf * BN * LDSK;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (vmask & (1u << i)) {
-                v = ra[i];
-                if (has_gn) {
-                    v.x = fmaf(v.x, rsc[i].x, rsh[i].x);
-                    v.y = fmaf(v.y, rsc[i].y, rsh[i].y);
-                    v.z = fmaf(v.z, rsc[i].z, rsh[i].z);
-                    v.w = fmaf(v.w, rsc[i].w, rsh[i].w);
-                    if (p.swish) {
-                        v.x = swish_f(v.x); v.y = swish_f(v.y);
-                        v.z = swish_f(v.z); v.w = swish_f(v.w);
-                    }
-                }
-            }
-            *reinterpret_cast<float4 *>(Ad + (r0 + 32 * i) * LDSK + 4 * q) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            *reinterpret_cast<float4 *>(Bd + (r0 + 32 * i) * LDSK + 4 * q) = rb[i];
-        }
-    };
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -173,68 +126,157 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    issue_loads(0);
-    stage_to_lds(0);
+    // The three pipeline stages are macros, not lambdas: arrays captured by reference in a lambda
+    // were left in scratch memory by hipcc (ROCm 7.2), which serialised every K-step on the loads.
+
+    // Branch-free tile fetch: out-of-window taps load a clamped (valid) address and are zeroed
+    // when the tile is written to LDS, so the main loop is one basic block.
+#define SR3_ISSUE_LOADS(KIDX)                                                                      \
+    {                                                                                              \
+        const int kidx_ = (KIDX);                                                                  \
+        const int cc_ = kidx_ / taps;                                                              \
+        const int tap_ = kidx_ - cc_ * taps;                                                       \
+        const int c0_ = cc_ * BK;                                                                  \
+        const int dy_ = tap_ / p.ks, dx_ = tap_ - dy_ * p.ks;                                      \
+        const bool first_ = c0_ < p.C0;                                                            \
+        const float *src_ = first_ ? p.in0 : p.in1;                                                \
+        const int Cs_ = first_ ? p.C0 : p.C1;                                                      \
+        const int cl_ = first_ ? c0_ : c0_ - p.C0;                                                 \
+        vmask = 0;                                                                                 \
+        static_for<AR>([&](auto ic) {                                                              \
+            constexpr int i = decltype(ic)::value;                                                 \
+            const int uy = a_uy[i] + dy_, ux = a_ux[i] + dx_;                                      \
+            const bool ok = (unsigned)uy < (unsigned)Hv && (unsigned)ux < (unsigned)Wv;            \
+            const int iy = min(max(uy, 0), Hv - 1) >> p.up2, ix = min(max(ux, 0), Wv - 1) >> p.up2; \
+            const size_t off = ((size_t)(a_n[i] * p.Hin + iy) * p.Win + ix) * Cs_ + cl_ + 4 * q;   \
+            ra[i] = *reinterpret_cast<const f32x4 *>(src_ + off);                                 \
+            vmask |= ok ? (1u << i) : 0u;                                                          \
+            if (MODE != 0) {                                                                       \
+                const size_t go = (size_t)a_n[i] * Cin + c0_ + 4 * q;                              \
+                rsc[i] = *reinterpret_cast<const f32x4 *>(p.gn_scale + go);                       \
+                rsh[i] = *reinterpret_cast<const f32x4 *>(p.gn_shift + go);                       \
+            }                                                                                      \
+        });                                                                                        \
+        static_for<BR>([&](auto ic) {                                                              \
+            constexpr int i = decltype(ic)::value;                                                 \
+            rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr[i] + (size_t)tap_ * p.Cout * Cin + c0_); \
+        });                                                                                        \
+    }
+
+#define SR3_STAGE_TO_LDS(BUF)                                                                      \
+    {                                                                                              \
+        float *Ad = As + (BUF) * BM * LDSK;                                                        \
+        float *Bd = Bs + (BUF) * BN * LDSK;                                                        \
+        static_for<AR>([&](auto ic) {                                                              \
+            constexpr int i = decltype(ic)::value;                                                 \
+            f32x4 v = ra[i];                                                                      \
+            if (MODE != 0) {                                                                       \
+                v.x = fmaf(v.x, rsc[i].x, rsh[i].x);                                               \
+                v.y = fmaf(v.y, rsc[i].y, rsh[i].y);                                               \
+                v.z = fmaf(v.z, rsc[i].z, rsh[i].z);                                               \
+                v.w = fmaf(v.w, rsc[i].w, rsh[i].w);                                               \
+            }                                                                                      \
+            if (MODE == 2) {                                                                       \
+                v.x = swish_f(v.x); v.y = swish_f(v.y);                                            \
+                v.z = swish_f(v.z); v.w = swish_f(v.w);                                            \
+            }                                                                                      \
+            const bool ok = (vmask >> i) & 1u;                                                     \
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; \
+            *reinterpret_cast<f32x4 *>(Ad + (r0 + 32 * i) * LDSK + 4 * q) = v;                    \
+        });                                                                                        \
+        static_for<BR>([&](auto ic) {                                                              \
+            constexpr int i = decltype(ic)::value;                                                 \
+            *reinterpret_cast<f32x4 *>(Bd + (r0 + 32 * i) * LDSK + 4 * q) = rb[i];                \
+        });                                                                                        \
+    }
+
+#define SR3_MMA_GROUPS(CUR, KK0, KK1)                                                              \
+    {                                                                                              \
+        const float *Ab = As + (CUR) * BM * LDSK + (wm * WM + li) * LDSK + 4 * lh;                 \
+        const float *Bb = Bs + (CUR) * BN * LDSK + (wn * WN + li) * LDSK + 4 * lh;                 \
+        _Pragma("unroll") for (int kk = (KK0); kk < (KK1); ++kk) {                                 \
+            f32x4 av[MI], bv[NI];                                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                      \
+                av[mi] = *reinterpret_cast<const f32x4 *>(Ab + mi * 32 * LDSK + kk * 8);          \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                      \
+                bv[ni] = *reinterpret_cast<const f32x4 *>(Bb + ni * 32 * LDSK + kk * 8);          \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                    \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].z, bv[ni].z, acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].w, bv[ni].w, acc[mi][ni], 0, 0, 0); \
+            }                                                                                      \
+        }                                                                                          \
+    }
+
+    // Pipeline: while tile kt is multiplied out of LDS buffer kt&1, tile kt+1 (already in
+    // registers) is transformed and written to the other buffer in the shadow of the MFMAs, then
+    // the global loads of tile kt+2 are issued. Loads past the end re-fetch the last tile (unused).
+    SR3_ISSUE_LOADS(0)
+    SR3_STAGE_TO_LDS(0)
+    SR3_ISSUE_LOADS(min(1, nk - 1))
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1) < nk;
-        if (more) issue_loads(kt + 1);
-
-        const float *Ab = As + cur * BM * LDSK + (wm * WM + li) * LDSK + 4 * lh;
-        const float *Bb = Bs + cur * BN * LDSK + (wn * WN + li) * LDSK + 4 * lh;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 av[MI], bv[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                av[mi] = *reinterpret_cast<const float4 *>(Ab + mi * 32 * LDSK + kk * 8);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                bv[ni] = *reinterpret_cast<const float4 *>(Bb + ni * 32 * LDSK + kk * 8);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].z, bv[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].w, bv[ni].w, acc[mi][ni], 0, 0, 0);
-                }
-        }
-        if (more) stage_to_lds(cur ^ 1);
+        SR3_MMA_GROUPS(cur, 0, BK / 16)
+        SR3_STAGE_TO_LDS(cur ^ 1)
+        SR3_MMA_GROUPS(cur, BK / 16, BK / 8)
+        SR3_ISSUE_LOADS(min(kt + 2, nk - 1))
         __syncthreads();
     }
+#undef SR3_ISSUE_LOADS
+#undef SR3_STAGE_TO_LDS
+#undef SR3_MMA_GROUPS
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue -------------------------------------------------------------------------
+    // LDS is free now: one image index per tile row (one integer division per thread).
+    int *rowimg = reinterpret_cast<int *>(smem);
+    if (p.chan_bias != nullptr) {
+        if (tid < BM) rowimg[tid] = min(m0 + tid, M - 1) / HWo;
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * WN + ni * 32 + li;
-        if (n >= p.Cout) continue;
-        const float bs = p.bias ? p.bias[n] : 0.f;
+        const int nc = min(n, p.Cout - 1);
+        const float bs = p.bias ? p.bias[nc] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            const int rbase = wm * WM + mi * 32 + 4 * lh;
+            float add[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add[r] = bs;
+            if (p.resid != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(m0 + rbase + (r & 3) + 8 * (r >> 2), M - 1);
+                    add[r] += p.resid[(size_t)m * p.Cout + nc];
+                }
+            }
+            if (p.chan_bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int img = rowimg[rbase + (r & 3) + 8 * (r >> 2)];
+                    add[r] += p.chan_bias[(size_t)img * p.chan_bias_stride + nc];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) {
-                    float v = acc[mi][ni][r] + bs;
-                    if (p.chan_bias) v += p.chan_bias[(size_t)(m / HWo) * p.chan_bias_stride + n];
-                    const size_t o = (size_t)m * p.Cout + n;
-                    if (p.resid) v += p.resid[o];
-                    p.out[o] = v;
-                }
+                const int m = m0 + rbase + (r & 3) + 8 * (r >> 2);
+                if (m < M && n < p.Cout) p.out[(size_t)m * p.Cout + n] = acc[mi][ni][r] + add[r];
             }
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-void launch_cfg(const ConvParams &p, hipStream_t s) {
+template <int BM, int BN, int WGM, int WGN, int MODE>
+void launch_inst(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDSK * sizeof(float);
-    auto kern = conv_igemm_f32<BM, BN, WGM, WGN>;
+    auto kern = conv_igemm_f32<BM, BN, WGM, WGN, MODE>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -243,6 +285,13 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
     const int M = p.B * p.Hout * p.Wout;
     const int tilesM = (M + BM - 1) / BM, tilesN = (p.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), lds, s, p);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_cfg(const ConvParams &p, hipStream_t s) {
+    if (p.gn_scale == nullptr) launch_inst<BM, BN, WGM, WGN, 0>(p, s);
+    else if (!p.swish) launch_inst<BM, BN, WGM, WGN, 1>(p, s);
+    else launch_inst<BM, BN, WGM, WGN, 2>(p, s);
 }
 
 } // namespace

@@ -10,6 +10,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -74,7 +76,8 @@ struct Module {
 
 enum Family { F_CONV = 0, F_GN = 1, F_ATTN = 2, F_EMBED = 3, F_MISC = 4 };
 
-struct ProfRec { int fam; hipEvent_t a, b; double flops; };
+struct ProfRec { int fam; hipEvent_t a, b; double flops; std::string tag; };
+struct ProfAgg { double ms = 0, flops = 0; int64_t n = 0; };
 
 } // namespace
 
@@ -118,6 +121,7 @@ struct sr3_ctx {
     std::vector<hipEvent_t> ev_pool;
     double acc_ms[SR3_N_FAMILIES] = {0}, acc_flops[SR3_N_FAMILIES] = {0};
     int64_t acc_n[SR3_N_FAMILIES] = {0};
+    std::map<std::string, ProfAgg> by_tag;   // per distinct launch shape
 
     hipEvent_t get_event() {
         if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
@@ -127,13 +131,14 @@ struct sr3_ctx {
     }
     void pbegin(int fam) {
         if (!prof) return;
-        ProfRec r{fam, get_event(), get_event(), 0.0};
+        ProfRec r{fam, get_event(), get_event(), 0.0, std::string()};
         (void)hipEventRecord(r.a, stream);
         recs.push_back(r);
     }
-    void pend(double flops = 0.0) {
+    void pend(double flops = 0.0, const char *tag = nullptr) {
         if (!prof) return;
         recs.back().flops = flops;
+        if (tag) recs.back().tag = tag;
         (void)hipEventRecord(recs.back().b, stream);
     }
     void pflush() {
@@ -145,6 +150,10 @@ struct sr3_ctx {
             acc_ms[r.fam] += ms;
             acc_flops[r.fam] += r.flops;
             acc_n[r.fam] += 1;
+            if (!r.tag.empty()) {
+                ProfAgg &g = by_tag[r.tag];
+                g.ms += ms; g.flops += r.flops; g.n += 1;
+            }
             ev_pool.push_back(r.a);
             ev_pool.push_back(r.b);
         }
@@ -420,7 +429,12 @@ void run_conv(sr3_ctx *c, const Src &s, const ConvRef &cv, int B, int stride, in
     p.out = out; p.Cout = cv.cout;
     c->pbegin(F_CONV);
     launch_conv(p, c->stream);
-    c->pend(2.0 * (double)B * ho * wo * cv.cout * (double)(cv.ks * cv.ks) * cv.cin);
+    if (c->prof) {
+        char tag[160];
+        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d gn%d res%d", cv.ks, stride, up2, ho, wo,
+                 cv.cin, s.c0, s.c1, cv.cout, gn ? 1 : 0, resid ? 1 : 0);
+        c->pend(2.0 * (double)B * ho * wo * cv.cout * (double)(cv.ks * cv.ks) * cv.cin, tag);
+    }
 }
 
 // ResnetBlock.forward (unet.py:105-110) + SelfAttention.forward (unet.py:123-142)
@@ -762,6 +776,21 @@ int sr3_profile_reset(sr3_ctx *c) {
     if (!c) return fail("null context");
     c->pflush();
     for (int i = 0; i < SR3_N_FAMILIES; ++i) { c->acc_ms[i] = 0; c->acc_flops[i] = 0; c->acc_n[i] = 0; }
+    c->by_tag.clear();
+    return 0;
+}
+int sr3_profile_dump_csv(sr3_ctx *c, const char *path) {
+    if (!c || !path) return fail("null argument");
+    c->pflush();
+    FILE *f = fopen(path, "w");
+    if (!f) return fail("cannot open %s", path);
+    fprintf(f, "shape,launches,total_ms,avg_ms,gflop_per_launch,tflops\n");
+    for (auto &kv : c->by_tag) {
+        const ProfAgg &g = kv.second;
+        fprintf(f, "%s,%lld,%.4f,%.4f,%.3f,%.2f\n", kv.first.c_str(), (long long)g.n, g.ms, g.ms / g.n,
+                g.flops / g.n / 1e9, g.ms > 0 ? g.flops / (g.ms * 1e-3) / 1e12 : 0.0);
+    }
+    fclose(f);
     return 0;
 }
 int sr3_profile_get(sr3_ctx *c, int family, double *total_ms, int64_t *launches, double *flops) {
@@ -806,6 +835,60 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipFree(dw));
     if (db) HIP_OK(hipFree(db));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// Times `iters` launches of one conv shape on scratch buffers (uninitialised weights are fine for
+// timing: f32 MFMA time does not depend on the data). mode 0 raw, 1 GN affine, 2 GN affine + Swish.
+int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout, int ks, int stride, int up2,
+                   int mode, int with_resid, int with_chan_bias, int iters, float *avg_ms) {
+    if (!c || !avg_ms) return fail("null argument");
+    if ((C0 % 32) || (C1 % 32) || C0 <= 0) return fail("sr3_bench_conv: channels must be multiples of 32");
+    HIP_OK(hipSetDevice(c->device));
+    const int Cin = C0 + C1, pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
+    const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
+    const size_t n_in0 = (size_t)B * Hin * Win * C0, n_in1 = (size_t)B * Hin * Win * C1;
+    const size_t n_out = (size_t)B * Ho * Wo * Cout, n_w = (size_t)ks * ks * Cout * Cin;
+    float *in0, *in1 = nullptr, *w, *bias, *out, *res = nullptr, *sc, *sh, *cb;
+    HIP_OK(hipMalloc(&in0, n_in0 * 4));
+    if (C1) HIP_OK(hipMalloc(&in1, n_in1 * 4));
+    HIP_OK(hipMalloc(&w, n_w * 4));
+    HIP_OK(hipMalloc(&bias, (size_t)Cout * 4));
+    HIP_OK(hipMalloc(&out, n_out * 4));
+    HIP_OK(hipMalloc(&res, n_out * 4));
+    HIP_OK(hipMalloc(&sc, (size_t)B * Cin * 4));
+    HIP_OK(hipMalloc(&sh, (size_t)B * Cin * 4));
+    HIP_OK(hipMalloc(&cb, (size_t)B * Cout * 4));
+    // pseudo-random but finite contents (random data: MI355X guide rule 25)
+    launch_philox_normal(1, 0, 0, (int)std::min<size_t>(n_in0, 1u << 30), in0, c->stream);
+    if (C1) launch_philox_normal(2, 0, 0, (int)std::min<size_t>(n_in1, 1u << 30), in1, c->stream);
+    launch_philox_normal(3, 0, 0, (int)n_w, w, c->stream);
+    launch_philox_normal(4, 0, 0, Cout, bias, c->stream);
+    launch_philox_normal(5, 0, 0, (int)std::min<size_t>(n_out, 1u << 30), res, c->stream);
+    launch_philox_normal(6, 0, 0, B * Cin, sc, c->stream);
+    launch_philox_normal(7, 0, 0, B * Cin, sh, c->stream);
+    launch_philox_normal(8, 0, 0, B * Cout, cb, c->stream);
+    ConvParams p;
+    p.in0 = in0; p.in1 = in1; p.C0 = C0; p.C1 = C1; p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
+    p.ks = ks; p.stride = stride; p.up2 = up2; p.w = w; p.bias = bias;
+    p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
+    p.resid = with_resid ? res : nullptr;
+    p.gn_scale = mode ? sc : nullptr; p.gn_shift = mode ? sh : nullptr; p.swish = mode == 2;
+    p.out = out; p.Cout = Cout;
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch_conv(p, c->stream);
+    HIP_OK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) launch_conv(p, c->stream);
+    HIP_OK(hipEventRecord(e1, c->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+    for (float *q : {in0, in1, w, bias, out, res, sc, sh, cb})
+        if (q) HIP_OK(hipFree(q));
     HIP_OK(hipGetLastError());
     return 0;
 }

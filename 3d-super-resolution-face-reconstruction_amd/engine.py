@@ -188,6 +188,16 @@ class Engine:
             out[fam] = {"ms": ms.value, "launches": int(n.value), "flops": fl.value}
         return out
 
+    def bench_conv(self, B, H, W, C0, C1, Cout, ks=3, stride=1, up2=0, mode=2, resid=0, chan_bias=0,
+                   iters=10) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.sr3_bench_conv(self.ctx, B, H, W, C0, C1, Cout, ks, stride, up2, mode,
+                                           resid, chan_bias, iters, C.byref(ms)))
+        return ms.value
+
+    def profile_dump_csv(self, path: str):
+        _lib.check(self.lib.sr3_profile_dump_csv(self.ctx, path.encode()))
+
     # ---- single ops (numpy in / numpy out; NHWC) --------------------------------------------
     def op_conv2d(self, x0, weight, bias=None, x1=None, stride=1, up2=False, gn_scale=None,
                   gn_shift=None, swish=False, chan_bias=None, resid=None) -> np.ndarray:

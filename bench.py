@@ -158,6 +158,8 @@ def main():
         eng.profile_enable(True)
         run_steps(K, t_next)
         prof = eng.profile_get()
+        if os.environ.get("SR3_PROFILE_CSV"):
+            eng.profile_dump_csv(os.environ["SR3_PROFILE_CSV"])
         eng.profile_enable(False)
         conv = prof["conv_igemm"]
         n = max(1, conv["launches"])

@@ -126,6 +126,13 @@ int sr3_profile_reset(sr3_ctx *ctx);
  * Synchronises the stream. flops = algorithmic 2*MAC of the launches (0 for non-GEMM families). */
 int sr3_profile_get(sr3_ctx *ctx, int family, double *total_ms, int64_t *launches, double *flops);
 #define SR3_N_FAMILIES 5
+/* per distinct conv launch shape: launches, total/avg ms, GFLOP per launch, TFLOP/s (CSV) */
+int sr3_profile_dump_csv(sr3_ctx *ctx, const char *path);
+
+/* Kernel micro-benchmark: average ms of `iters` launches of one conv shape on scratch buffers
+ * (mode 0 raw input, 1 GroupNorm affine, 2 affine + Swish). */
+int sr3_bench_conv(sr3_ctx *ctx, int B, int Hin, int Win, int C0, int C1, int Cout, int ks, int stride,
+                   int up2, int mode, int with_resid, int with_chan_bias, int iters, float *avg_ms);
 
 /* ---- single ops through the same kernels (parity tests call these) ------------------------ */
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark for the implicit-GEMM conv (development tool; run on the GPU box):
+    python tools/conv_bench.py [--iters N] [--set main|all]
+Prints ms and TFLOP/s per shape of the B=64, 128x128 SR3 step."""
+import argparse
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+PKG = "3d-super-resolution-face-reconstruction_amd"
+
+# B, H, W, C0, C1, Cout, ks, stride, up2, mode, resid, chan_bias
+MAIN = [
+    (64, 128, 128, 64, 0, 64, 3, 1, 0, 2, 1, 0),
+    (64, 128, 128, 64, 0, 64, 3, 1, 0, 0, 0, 0),
+    (64, 128, 128, 128, 64, 64, 3, 1, 0, 2, 0, 1),
+    (64, 64, 64, 128, 0, 128, 3, 1, 0, 2, 1, 0),
+    (64, 64, 64, 128, 0, 128, 3, 1, 0, 0, 0, 0),
+    (64, 32, 32, 256, 0, 256, 3, 1, 0, 2, 1, 0),
+    (64, 16, 16, 512, 0, 512, 3, 1, 0, 2, 1, 0),
+    (64, 16, 16, 512, 0, 512, 3, 1, 0, 0, 0, 0),
+    (64, 8, 8, 512, 0, 512, 3, 1, 0, 2, 1, 0),
+    (64, 16, 16, 512, 0, 512, 3, 1, 1, 0, 0, 0),
+    (64, 64, 64, 128, 0, 128, 3, 1, 1, 0, 0, 0),
+    (64, 128, 128, 64, 0, 3, 3, 1, 0, 2, 0, 0),
+    (64, 128, 128, 32, 0, 64, 3, 1, 0, 0, 0, 0),
+]
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", type=str, default="", help="comma list of shape indices")
+    args = ap.parse_args()
+    synth = importlib.import_module(PKG + ".synth")
+    Engine = importlib.import_module(PKG + ".engine").Engine
+    e = Engine(synth.tiny_unet_config(), 0)
+    shapes = MAIN if not args.only else [MAIN[int(i)] for i in args.only.split(",")]
+    for (B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb) in shapes:
+        ms = e.bench_conv(B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb, args.iters)
+        Ho, Wo = (H * (2 if up else 1)) // st, (W * (2 if up else 1)) // st
+        fl = 2.0 * B * Ho * Wo * Cout * ks * ks * (C0 + C1)
+        print(f"B{B} {H}x{W} cin{C0}+{C1} cout{Cout} k{ks} s{st} u{up} mode{mode} res{rs} cb{cb}: "
+              f"{ms:8.4f} ms  {fl / ms / 1e9:7.2f} TFLOP/s", flush=True)
+    e.close()
