@@ -1,0 +1,78 @@
+"""Multi-process path on CPU (gloo, world_size 2 and 3): batch sharding + the single end-of-loop
+all-gather + rank-invariant RNG offsets. The per-rank sampler is a stand-in function here (the HIP
+sampler needs a GPU); the collective code is the product's (dist.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import pkg
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _fake_sampler(x, off):
+    # deterministic function of the image and its GLOBAL index, like the Philox image_offset
+    idx = torch.arange(off, off + x.shape[0], dtype=torch.float32).view(-1, 1, 1, 1)
+    return x * 0.5 + idx
+
+
+def _worker(rank, world, port, n, q):
+    import importlib, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    d = importlib.import_module("3d-super-resolution-face-reconstruction_amd.dist")
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    d.init_from_env("gloo")
+    x = torch.arange(n * 3 * 2 * 2, dtype=torch.float32).reshape(n, 3, 2, 2)
+    out = d.sharded_super_resolution(_fake_sampler, x)
+    a, b = d.shard_bounds(n, world, rank)
+    q.put((rank, out.numpy(), (a, b)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 8), (2, 5), (3, 7)])
+def test_sharded_gather(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = torch.arange(n * 3 * 2 * 2, dtype=torch.float32).reshape(n, 3, 2, 2)
+    want = _fake_sampler(x, 0).numpy()
+    covered = []
+    for rank, out, (a, b) in res:
+        np.testing.assert_array_equal(out, want)      # every rank holds the full gathered batch
+        covered += list(range(a, b))
+    assert sorted(covered) == list(range(n))
+
+
+def test_shard_bounds_properties():
+    d = pkg("dist")
+    for n in (0, 1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            b = [d.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [y - x for x, y in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_passthrough():
+    d = pkg("dist")
+    x = torch.randn(4, 3, 2, 2)
+    assert torch.equal(d.sharded_super_resolution(lambda t, off: t + off, x), x)
+    assert d.all_gather_images(x, 4) is x
