@@ -27,6 +27,7 @@ struct ConvParams {
     int swish;
     float *out;             // [B][Hout][Wout][Cout]
     int Cout;
+    int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
 // returns the algorithmic FLOPs (2*MAC) of the launch
 double launch_conv(const ConvParams &p, hipStream_t s);
