@@ -65,9 +65,9 @@ PROTOTYPES = {
     "sr3_profile_reset": (_I, [_P]),
     "sr3_profile_get": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sr3_profile_dump_csv": (_I, [_P, C.c_char_p]),
-    "sr3_bench_conv": (_I, [_P] + [_I] * 13 + [C.POINTER(C.c_float)]),
+    "sr3_bench_conv": (_I, [_P] + [_I] * 13 + [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sr3_op_conv2d": (_I, [_P, _F, _I, _F, _I, _I, _I, _I, _F, _F, _I, _I, _I, _I, _F, _F, _I, _F, _F, _F]),
-    "sr3_op_groupnorm_affine": (_I, [_P, _F, _I, _F, _I, _I, _I, _I, _F, _F, _F, _F]),
+    "sr3_op_groupnorm_affine": (_I, [_P, _F, _I, _F, _I, _I, _I, _I, _I, _F, _F, _F, _F]),
     "sr3_op_attention": (_I, [_P, _F, _I, _I, _I, _F]),
     "sr3_op_noise_embed": (_I, [_P, _F, _I, _F, _F]),
     "sr3_chan_bias_total": (_I, [_P]),

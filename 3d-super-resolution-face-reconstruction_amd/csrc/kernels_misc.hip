@@ -38,12 +38,12 @@ __device__ __forceinline__ void wf_merge(Wf &a, const Wf &b) {
     a.n = n;
 }
 
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict__ in0, int C0,
-                                                         const float *__restrict__ in1, int C1,
-                                                         int HW, int groups, int slices,
-                                                         float *__restrict__ part) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(const TDesc in0, const TDesc in1, int groups,
+                                                         int slices, float *__restrict__ part) {
     __shared__ float sn[256], smean[256], sm2[256];
+    const int C0 = in0.C, C1 = in1.p ? in1.C : 0;
     const int C = C0 + C1, Cg = C / groups;
+    const int W = in0.W, HW = in0.H * in0.W;
     const int slice = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
     const int per = (HW + slices - 1) / slices;
     const int p0 = slice * per;
@@ -56,13 +56,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict
         const int pl = t / cw;
         Wf s = {0.f, 0.f, 0.f};
         if (pl < plw) {
-            const float *src;
-            size_t cs;
-            int cl;
-            if (c < C0) { src = in0; cs = C0; cl = c; } else { src = in1; cs = C1; cl = c - C0; }
-            src += (size_t)n * HW * cs + cl;
-#pragma unroll 8
-            for (int p = p0 + pl; p < p1; p += plw) wf_push(s, src[(size_t)p * cs]);
+            const TDesc &d = (c < C0) ? in0 : in1;
+            const int cl = (c < C0) ? c : c - C0;
+            const size_t cs = d.C;
+            const int Wp = d.Wp();
+            int pp = p0 + pl;
+            int y = pp / W, x = pp - y * W;
+            const float *src = d.p + d.pix(n, 0, 0) * cs + cl;   // interior origin of image n
+#pragma unroll 4
+            for (; pp < p1; pp += plw) {
+                wf_push(s, src[((size_t)y * Wp + x) * cs]);
+                x += plw;
+                while (x >= W) { x -= W; ++y; }
+            }
         }
         sn[t] = s.n; smean[t] = s.mean; sm2[t] = s.m2;
         __syncthreads();
@@ -125,14 +131,64 @@ static int gn_slices(int B, int HW) {
 
 size_t gn_workspace_floats(int B, int groups) { return (size_t)B * GN_MAX_SLICES * groups * 3; }
 
-void launch_groupnorm_affine(const float *in0, int C0, const float *in1, int C1, int B, int HW,
-                             int groups, const float *gamma, const float *beta, float eps,
-                             float *part, float *scale, float *shift, hipStream_t s) {
-    const int slices = gn_slices(B, HW);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, C0, in1, C1, HW,
-                       groups, slices, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, part,
-                       C0 + C1, groups, slices, gamma, beta, eps, scale, shift);
+void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int groups, const float *gamma,
+                             const float *beta, float eps, float *part, float *scale, float *shift,
+                             hipStream_t s) {
+    const int slices = gn_slices(B, in0.H * in0.W);
+    const int C = in0.C + (in1.p ? in1.C : 0);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, in1, groups, slices, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, part, C,
+                       groups, slices, gamma, beta, eps, scale, shift);
+}
+
+// -------------------------------------------------------------------------------------------------
+// GroupNorm apply (+ Swish) (+ channel concat) into a zero-bordered tensor: the activated input of
+// a conv (reference Block: GroupNorm -> Swish -> Conv, unet.py:84-87). HBM-bound element-wise pass;
+// the VALU work lives here because it would serialise with the f32 MFMAs inside the conv kernel.
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float swish_fast(float x) {
+    // x * sigmoid(x); v_exp_f32 / v_rcp_f32 are 1 ulp on gfx950
+    return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, const TDesc out) {
+    // grid: x = chunks of (pixel-in-row, channel quad), y = n * H + row
+    const int C0 = in0.C, C = out.C, C4 = C >> 2;
+    const int n = blockIdx.y / out.H, y = blockIdx.y - n * out.H;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= out.W * C4) return;
+    const int x = item / C4;
+    const int c = (item - x * C4) << 2;
+    const float4 *src = (c < C0)
+        ? reinterpret_cast<const float4 *>(in0.p + in0.pix(n, y, x) * C0 + c)
+        : reinterpret_cast<const float4 *>(in1.p + in1.pix(n, y, x) * in1.C + (c - C0));
+    float4 v = *src;
+    if (MODE != 0) {
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + (size_t)n * C + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + (size_t)n * C + c);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    }
+    if (MODE == 2) {
+        v.x = swish_fast(v.x); v.y = swish_fast(v.y); v.z = swish_fast(v.z); v.w = swish_fast(v.w);
+    }
+    *reinterpret_cast<float4 *>(out.p + out.pix(n, y, x) * C + c) = v;
+}
+
+} // namespace
+
+void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
+                     int mode, const TDesc &out, hipStream_t s) {
+    const int items = out.W * (out.C >> 2);
+    const dim3 grid((items + 255) / 256, B * out.H);
+    if (mode == 0) hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(256), 0, s, in0, in1, scale, shift, out);
+    else if (mode == 1) hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(256), 0, s, in0, in1, scale, shift, out);
+    else hipLaunchKernelGGL(gn_apply_kernel<2>, grid, dim3(256), 0, s, in0, in1, scale, shift, out);
 }
 
 // =================================================================================================
@@ -303,30 +359,28 @@ void launch_noise_embed(const EmbedParams &p, int B, hipStream_t s) {
 // =================================================================================================
 namespace {
 
-__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int C, int HW, float *out,
-                                    int Cdst, int coff, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int C, const TDesc dst, int coff,
+                                    size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*H*W, c fastest
     if (i >= total) return;
+    const int HW = dst.H * dst.W;
     const int c = (int)(i % C);
     const size_t np = i / C;          // n*HW + p
-    const size_t n = np / HW, p = np - n * HW;
-    out[np * Cdst + coff + c] = in[(n * C + c) * HW + p];
+    const int n = (int)(np / HW), pp = (int)(np - (size_t)n * HW);
+    const int y = pp / dst.W, x = pp - y * dst.W;
+    dst.p[dst.pix(n, y, x) * dst.C + coff + c] = in[((size_t)n * C + c) * HW + pp];
 }
 
-__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, int C, int HW, int Csrc, int coff,
-                                    float *out, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void nhwc_to_nchw_kernel(const TDesc src, int coff, int C, float *out, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // NCHW order
     if (i >= total) return;
-    const size_t p = i % HW;
+    const int HW = src.H * src.W;
+    const int pp = (int)(i % HW);
     const size_t nc = i / HW;
-    const size_t n = nc / C;
-    const int c = (int)(nc - n * C);
-    out[i] = in[(n * HW + p) * Csrc + coff + c];
-}
-
-__global__ void fill_zero_kernel(float *p, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.f;
+    const int n = (int)(nc / C);
+    const int c = (int)(nc - (size_t)n * C);
+    const int y = pp / src.W, x = pp - y * src.W;
+    out[i] = src.p[src.pix(n, y, x) * src.C + coff + c];
 }
 
 // Philox4x32-10 (Salmon et al. 2011). CPU twin: oracle/philox.py.
@@ -367,39 +421,43 @@ __global__ void philox_normal_kernel(uint64_t seed, uint64_t image, uint32_t dra
     if (i < n) out[i] = philox_normal(seed, image, draw, (uint32_t)i);
 }
 
-__global__ void init_state_kernel(float *state, int Cs, int xoff, int C, const float *noise,
-                                  uint64_t seed, uint64_t image_offset, int HW, size_t total) {
+__global__ void init_state_kernel(const TDesc state, int xoff, int C, const float *noise, uint64_t seed,
+                                  uint64_t image_offset, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW, NCHW order
     if (i >= total) return;
-    const size_t p = i % HW;
+    const int HW = state.H * state.W;
+    const int pp = (int)(i % HW);
     const size_t nc = i / HW;
-    const size_t n = nc / C;
-    const int c = (int)(nc - n * C);
-    const float z = noise ? noise[i] : philox_normal(seed, image_offset + n, 0u, (uint32_t)(c * HW + p));
-    state[(n * HW + p) * Cs + xoff + c] = z;
+    const int n = (int)(nc / C);
+    const int c = (int)(nc - (size_t)n * C);
+    const int y = pp / state.W, x = pp - y * state.W;
+    const float z = noise ? noise[i] : philox_normal(seed, image_offset + n, 0u, (uint32_t)(c * HW + pp));
+    state.p[state.pix(n, y, x) * state.C + xoff + c] = z;
 }
 
 // One p_sample tail (reference diffusion.py:144-151 predict_start_from_noise, :175-176 clamp,
 // :153-162 q_posterior, :182-187 p_sample), element-wise in the reference's operation order.
-__global__ void ddpm_update_kernel(const UpdateParams u, int HW, size_t total) {
+__global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW, NCHW order
     if (i >= total) return;
-    const size_t p = i % HW;
+    const int HW = u.state.H * u.state.W;
+    const int pp = (int)(i % HW);
     const size_t nc = i / HW;
-    const size_t n = nc / u.C;
-    const int c = (int)(nc - n * u.C);
-    const size_t si = (n * HW + p) * u.Cs + u.xoff + c;
-    const float x = u.state[si];
-    const float e = u.eps[(n * HW + p) * u.Ce + c];
+    const int n = (int)(nc / u.C);
+    const int c = (int)(nc - (size_t)n * u.C);
+    const int y = pp / u.state.W, xx = pp - y * u.state.W;
+    const size_t si = u.state.pix(n, y, xx) * u.state.C + u.xoff + c;
+    const float x = u.state.p[si];
+    const float e = u.eps.p[u.eps.pix(n, y, xx) * u.eps.C + c];
     float x0 = __fsub_rn(__fmul_rn(u.a, x), __fmul_rn(u.b, e));
     x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
     float v = __fadd_rn(__fmul_rn(u.c1, x0), __fmul_rn(u.c2, x));
     if (u.sigma != 0.f) {
         const float z = u.noise ? u.noise[i]
-                                : philox_normal(u.seed, u.image_offset + n, u.draw, (uint32_t)(c * HW + p));
+                                : philox_normal(u.seed, u.image_offset + n, u.draw, (uint32_t)(c * HW + pp));
         v = __fadd_rn(v, __fmul_rn(z, u.sigma));
     }
-    u.state[si] = v;
+    u.state.p[si] = v;
     if (u.frame) u.frame[i] = v;
 }
 
@@ -407,33 +465,25 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 } // namespace
 
-void launch_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, int Cdst, int coff,
-                         hipStream_t s) {
-    const size_t total = (size_t)B * C * H * W;
+void launch_nchw_to_nhwc(const float *in, int B, int C, const TDesc &dst, int coff, hipStream_t s) {
+    const size_t total = (size_t)B * C * dst.H * dst.W;
     if (!total) return;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk(total)), dim3(256), 0, s, in, C, H * W, out,
-                       Cdst, coff, total);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk(total)), dim3(256), 0, s, in, C, dst, coff, total);
 }
-void launch_nhwc_to_nchw(const float *in, int B, int C, int H, int W, int Csrc, int coff, float *out,
-                         hipStream_t s) {
-    const size_t total = (size_t)B * C * H * W;
+void launch_nhwc_to_nchw(const TDesc &src, int coff, int B, int C, float *out, hipStream_t s) {
+    const size_t total = (size_t)B * C * src.H * src.W;
     if (!total) return;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk(total)), dim3(256), 0, s, in, C, H * W, Csrc,
-                       coff, out, total);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk(total)), dim3(256), 0, s, src, coff, C, out, total);
 }
-void launch_fill_zero(float *p, size_t n, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(fill_zero_kernel, dim3(nblk(n)), dim3(256), 0, s, p, n);
+void launch_ddpm_update(const UpdateParams &p, int B, hipStream_t s) {
+    const size_t total = (size_t)B * p.C * p.state.H * p.state.W;
+    hipLaunchKernelGGL(ddpm_update_kernel, dim3(nblk(total)), dim3(256), 0, s, p, total);
 }
-void launch_ddpm_update(const UpdateParams &p, int B, int HW, hipStream_t s) {
-    const size_t total = (size_t)B * p.C * HW;
-    hipLaunchKernelGGL(ddpm_update_kernel, dim3(nblk(total)), dim3(256), 0, s, p, HW, total);
-}
-void launch_init_state(float *state, int Cs, int xoff, int C, const float *noise, uint64_t seed,
-                       uint64_t image_offset, int B, int HW, hipStream_t s) {
-    const size_t total = (size_t)B * C * HW;
-    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(total)), dim3(256), 0, s, state, Cs, xoff, C,
-                       noise, seed, image_offset, HW, total);
+void launch_init_state(const TDesc &state, int xoff, int C, const float *noise, uint64_t seed,
+                       uint64_t image_offset, int B, hipStream_t s) {
+    const size_t total = (size_t)B * C * state.H * state.W;
+    hipLaunchKernelGGL(init_state_kernel, dim3(nblk(total)), dim3(256), 0, s, state, xoff, C, noise, seed,
+                       image_offset, total);
 }
 void launch_philox_normal(uint64_t seed, uint64_t image, uint32_t draw, int n, float *out,
                           hipStream_t s) {

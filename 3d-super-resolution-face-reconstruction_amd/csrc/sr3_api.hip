@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 using namespace sr3;
@@ -69,8 +70,9 @@ struct Module {
     ResBlock rb;
     ConvRef conv;
     // workspace (set by ensure_workspace)
-    float *out = nullptr;     // module output
-    float *rb_out = nullptr;  // ResBlock output before attention (== out if no attention)
+    TDesc out;      // module output (zero-bordered)
+    TDesc rb_out;   // ResBlock output before attention (== out if no attention)
+    TDesc act1, act2, h1;   // activated conv inputs and the block1 output (per-shape buffers)
     int oc = 0, oh = 0, ow = 0;
 };
 
@@ -101,10 +103,12 @@ struct sr3_ctx {
     int wB = 0, wH = 0, wW = 0;
     char *arena = nullptr;
     uint64_t arena_bytes = 0;
-    float *x0 = nullptr;        // [B][HW][in_pad]: cond ‖ x ‖ zero pad (the UNet input and sampler state)
-    float *h1 = nullptr, *rbuf = nullptr, *qkvb = nullptr, *aob = nullptr;
+    TDesc x0;                   // [B][H+2][W+2][in_pad]: cond ‖ x ‖ zero pad (UNet input = sampler state)
+    TDesc eps;                  // [B][H][W][out_channel]
+    TDesc final_act;            // activated input of final_conv
+    float *rbuf = nullptr, *qkvb = nullptr, *aob = nullptr;
     float *gscale = nullptr, *gshift = nullptr, *gpart = nullptr;
-    float *temb = nullptr, *cbias = nullptr, *eps = nullptr, *nlb = nullptr;
+    float *temb = nullptr, *cbias = nullptr;
 
     // schedule
     int T = 0;
@@ -336,12 +340,27 @@ struct Carver {
     }
 };
 
+// per-shape buffer pool: tensors of one (C, H, W) that are never live at the same time share a
+// buffer; because the shape is fixed per buffer its zero border is never overwritten
+struct ShapePool {
+    std::map<std::tuple<int, int, int>, uint64_t> off;
+    uint64_t get(Carver &cv, int B, int C, int H, int W) {
+        auto key = std::make_tuple(C, H, W);
+        auto it = off.find(key);
+        if (it != off.end()) return it->second;
+        const uint64_t o = cv.take((uint64_t)B * (H + 2) * (W + 2) * C);
+        off[key] = o;
+        return o;
+    }
+};
+
 int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     if (c->arena && c->wB == B && c->wH == H && c->wW == W) return 0;
     const sr3_unet_cfg &g = c->cfg;
     const int div = 1 << (g.n_mults - 1);
     if (B <= 0 || H <= 0 || W <= 0 || (H % div) || (W % div))
         return fail("unsupported shape B=%d H=%d W=%d: H and W must be multiples of %d", B, H, W, div);
+    if ((uint64_t)B * (H + 2) * (W + 2) >= (1ull << 31)) return fail("B*H*W too large for 32-bit pixel indices");
     if (c->arena) {
         HIP_OK(hipStreamSynchronize(c->stream));
         HIP_OK(hipFree(c->arena));
@@ -349,10 +368,14 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     }
     // dry run over the graph for sizes
     Carver cv;
-    std::vector<uint64_t> out_off(c->mods.size()), rb_off(c->mods.size());
+    ShapePool acts, h1s;
+    const size_t nm = c->mods.size();
+    std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm);
     uint64_t max_rb = 0, max_qkv = 0, max_ao = 0;
     int h = H, w = W;
-    for (size_t i = 0; i < c->mods.size(); ++i) {
+    int cur_c = c->in_pad;
+    std::vector<int> feat_c;
+    for (size_t i = 0; i < nm; ++i) {
         Module &m = c->mods[i];
         int oc;
         if (m.kind == M_CONV_IN) { oc = m.conv.cout; }
@@ -360,143 +383,161 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         else if (m.kind == M_UP) { oc = m.conv.cout; h *= 2; w *= 2; }
         else {
             oc = m.rb.cout;
-            const uint64_t n = (uint64_t)B * h * w * oc;
+            a1_off[i] = acts.get(cv, B, m.rb.cin, h, w);
+            a2_off[i] = acts.get(cv, B, oc, h, w);
+            h1_off[i] = h1s.get(cv, B, oc, h, w);
+            const uint64_t n = (uint64_t)B * (h + 2) * (w + 2) * oc;
             if (n > max_rb) max_rb = n;
             if (m.rb.attn) {
-                if (3 * n > max_qkv) max_qkv = 3 * n;
-                if (n > max_ao) max_ao = n;
+                const uint64_t nu = (uint64_t)B * h * w * oc;
+                if (3 * nu > max_qkv) max_qkv = 3 * nu;
+                if (nu > max_ao) max_ao = nu;
                 if ((long)h * w > 1024) return fail("attention over %d tokens exceeds the 1024-token LDS tile", h * w);
             }
         }
         m.oc = oc; m.oh = h; m.ow = w;
-        const uint64_t n = (uint64_t)B * h * w * oc;
+        const uint64_t n = (uint64_t)B * (h + 2) * (w + 2) * oc;
         out_off[i] = cv.take(n);
         rb_off[i] = (m.kind == M_RES && m.rb.attn) ? cv.take(n) : out_off[i];
+        cur_c = oc;
     }
+    (void)cur_c;
     if (h != H || w != W) return fail("internal: UNet does not return to the input resolution");
+    const uint64_t o_fa = acts.get(cv, B, c->final_gn.C, H, W);
     const uint64_t HW = (uint64_t)H * W;
-    const uint64_t o_x0 = cv.take((uint64_t)B * HW * c->in_pad);
-    const uint64_t o_h1 = cv.take(max_rb), o_r = cv.take(max_rb);
+    const uint64_t o_x0 = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
+    const uint64_t o_r = cv.take(max_rb);
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
     const uint64_t o_gp = cv.take(gn_workspace_floats(B, g.norm_groups));
     const uint64_t o_te = cv.take((uint64_t)B * g.inner_channel);
     const uint64_t o_cb = cv.take((uint64_t)B * c->nf_total);
     const uint64_t o_eps = cv.take((uint64_t)B * HW * g.out_channel);
-    const uint64_t o_nl = cv.take((uint64_t)B);
     HIP_OK(hipMalloc(&c->arena, cv.off));
     c->arena_bytes = cv.off;
+    // zero everything once: the 1-pixel borders and the pad channels of x0 stay zero for the
+    // lifetime of the workspace (kernels only ever write interiors)
+    HIP_OK(hipMemsetAsync(c->arena, 0, cv.off, c->stream));
     auto at = [&](uint64_t o) { return reinterpret_cast<float *>(c->arena + o); };
-    for (size_t i = 0; i < c->mods.size(); ++i) {
-        c->mods[i].out = at(out_off[i]);
-        c->mods[i].rb_out = at(rb_off[i]);
+    auto desc = [&](uint64_t o, int C, int hh, int ww, int pad) {
+        TDesc d; d.p = at(o); d.C = C; d.H = hh; d.W = ww; d.pad = pad; return d;
+    };
+    for (size_t i = 0; i < nm; ++i) {
+        Module &m = c->mods[i];
+        m.out = desc(out_off[i], m.oc, m.oh, m.ow, 1);
+        m.rb_out = desc(rb_off[i], m.oc, m.oh, m.ow, 1);
+        if (m.kind == M_RES) {
+            m.act1 = desc(a1_off[i], m.rb.cin, m.oh, m.ow, 1);
+            m.act2 = desc(a2_off[i], m.oc, m.oh, m.ow, 1);
+            m.h1 = desc(h1_off[i], m.oc, m.oh, m.ow, 1);
+        }
     }
-    c->x0 = at(o_x0); c->h1 = at(o_h1); c->rbuf = at(o_r); c->qkvb = at(o_qkv); c->aob = at(o_ao);
+    c->x0 = desc(o_x0, c->in_pad, H, W, 1);
+    c->eps = desc(o_eps, g.out_channel, H, W, 0);
+    c->final_act = desc(o_fa, c->final_gn.C, H, W, 1);
+    c->rbuf = at(o_r); c->qkvb = at(o_qkv); c->aob = at(o_ao);
     c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
-    c->temb = at(o_te); c->cbias = at(o_cb); c->eps = at(o_eps); c->nlb = at(o_nl);
+    c->temb = at(o_te); c->cbias = at(o_cb);
     c->wB = B; c->wH = H; c->wW = W;
-    // the pad channels of the input tensor stay zero for the lifetime of the workspace
-    HIP_OK(hipMemsetAsync(c->x0, 0, (uint64_t)B * HW * c->in_pad * sizeof(float), c->stream));
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------
-struct Src { const float *p0; int c0; const float *p1; int c1; int h, w; };
+const TDesc kNone{};
 
-void run_gn(sr3_ctx *c, const Src &s, const GNRef &g, int B) {
+// GroupNorm statistics + apply (+Swish) (+concat) -> activated, zero-bordered conv input
+void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act) {
     c->pbegin(F_GN);
-    launch_groupnorm_affine(s.p0, s.c0, s.p1, s.c1, B, s.h * s.w, c->cfg.norm_groups,
-                            c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f, c->gpart,
-                            c->gscale, c->gshift, c->stream);
+    launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
+                            c->gpart, c->gscale, c->gshift, c->stream);
+    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, act, c->stream);
     c->pend();
 }
 
-void run_conv(sr3_ctx *c, const Src &s, const ConvRef &cv, int B, int stride, int up2, bool gn,
-              bool swish, const float *chan_bias, const float *resid, float *out, int ho, int wo) {
+void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int B, int stride, int up2,
+              const float *chan_bias, const TDesc &resid, const TDesc &out) {
     ConvParams p;
-    p.in0 = s.p0; p.in1 = s.p1; p.C0 = s.c0; p.C1 = s.c1;
-    p.B = B; p.Hin = s.h; p.Win = s.w; p.Hout = ho; p.Wout = wo;
+    p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
     p.w = c->params[cv.w].dev;
     p.bias = cv.b >= 0 ? c->params[cv.b].dev : nullptr;
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
-    p.resid = resid;
-    p.gn_scale = gn ? c->gscale : nullptr;
-    p.gn_shift = gn ? c->gshift : nullptr;
-    p.swish = swish ? 1 : 0;
-    p.out = out; p.Cout = cv.cout;
+    p.resid = resid; p.out = out;
     c->pbegin(F_CONV);
     launch_conv(p, c->stream);
     if (c->prof) {
         char tag[160];
-        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d gn%d res%d", cv.ks, stride, up2, ho, wo,
-                 cv.cin, s.c0, s.c1, cv.cout, gn ? 1 : 0, resid ? 1 : 0);
-        c->pend(2.0 * (double)B * ho * wo * cv.cout * (double)(cv.ks * cv.ks) * cv.cin, tag);
+        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d", cv.ks, stride, up2, out.H,
+                 out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0);
+        c->pend(2.0 * (double)B * out.H * out.W * cv.cout * (double)(cv.ks * cv.ks) * cv.cin, tag);
     }
 }
 
+TDesc unpadded(float *p, int C, int H, int W) {
+    TDesc d; d.p = p; d.C = C; d.H = H; d.W = W; d.pad = 0; return d;
+}
+
 // ResnetBlock.forward (unet.py:105-110) + SelfAttention.forward (unet.py:123-142)
-void run_res(sr3_ctx *c, Module &m, const Src &s, int B) {
+void run_res(sr3_ctx *c, Module &m, const TDesc &x, const TDesc &skip, int B) {
     const ResBlock &rb = m.rb;
-    const int h = s.h, w = s.w;
-    run_gn(c, s, rb.gn1, B);
-    run_conv(c, s, rb.c1, B, 1, 0, true, true, c->cbias + rb.nf_off, nullptr, c->h1, h, w);
-    const float *resid = s.p0;
+    const int h = m.oh, w = m.ow;
+    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1);
+    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1);
+    TDesc resid = x;
     if (rb.has_res) {
-        run_conv(c, s, rb.res, B, 1, 0, false, false, nullptr, nullptr, c->rbuf, h, w);
-        resid = c->rbuf;
+        TDesc r = m.rb_out; r.p = c->rbuf;          // same geometry as the block output
+        run_conv(c, x, skip, rb.res, B, 1, 0, nullptr, kNone, r);
+        resid = r;
     }
-    const Src hs{c->h1, rb.cout, nullptr, 0, h, w};
-    run_gn(c, hs, rb.gn2, B);
-    run_conv(c, hs, rb.c2, B, 1, 0, true, true, nullptr, resid, m.rb_out, h, w);
+    run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2);
+    run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, resid, m.rb_out);
     if (rb.attn) {
-        const Src xs{m.rb_out, rb.cout, nullptr, 0, h, w};
-        run_gn(c, xs, rb.agn, B);
-        run_conv(c, xs, rb.qkv, B, 1, 0, true, false, nullptr, nullptr, c->qkvb, h, w);
+        run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2);
+        const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
+        run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv);
         c->pbegin(F_ATTN);
         const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
         c->pend(fl);
-        const Src as{c->aob, rb.cout, nullptr, 0, h, w};
-        run_conv(c, as, rb.aout, B, 1, 0, false, false, nullptr, m.rb_out, m.out, h, w);
+        run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out);
     }
 }
 
 // UNet.forward body (unet.py:240-265): consumes c->x0 and c->cbias, leaves eps NHWC in c->eps
 void run_unet_body(sr3_ctx *c, int B, int H, int W) {
     std::vector<int> feats;
-    Src cur{c->x0, c->in_pad, nullptr, 0, H, W};
+    TDesc cur = c->x0;
     const int n_pre = c->n_downs + c->n_mid;
     for (int i = 0; i < (int)c->mods.size(); ++i) {
         Module &m = c->mods[i];
         const bool is_up_path = i >= n_pre;
         switch (m.kind) {
         case M_CONV_IN:
-            run_conv(c, cur, m.conv, B, 1, 0, false, false, nullptr, nullptr, m.out, m.oh, m.ow);
+            run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out);
             break;
         case M_DOWN:
-            run_conv(c, cur, m.conv, B, 2, 0, false, false, nullptr, nullptr, m.out, m.oh, m.ow);
+            run_conv(c, cur, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out);
             break;
         case M_UP:
-            run_conv(c, cur, m.conv, B, 1, 1, false, false, nullptr, nullptr, m.out, m.oh, m.ow);
+            run_conv(c, cur, kNone, m.conv, B, 1, 1, nullptr, kNone, m.out);
             break;
         case M_RES:
             if (is_up_path) {
                 Module &sk = c->mods[feats.back()];
                 feats.pop_back();
-                const Src cat{cur.p0, cur.c0, sk.out, sk.oc, cur.h, cur.w};
-                run_res(c, m, cat, B);
+                run_res(c, m, cur, sk.out, B);
             } else {
-                run_res(c, m, cur, B);
+                run_res(c, m, cur, kNone, B);
             }
             break;
         }
-        cur = Src{m.out, m.oc, nullptr, 0, m.oh, m.ow};
+        cur = m.out;
         if (i < c->n_downs) feats.push_back(i);
     }
-    run_gn(c, cur, c->final_gn, B);
-    run_conv(c, cur, c->final_conv, B, 1, 0, true, true, nullptr, nullptr, c->eps, H, W);
+    run_gn_act(c, cur, kNone, c->final_gn, B, 2, c->final_act);
+    run_conv(c, c->final_act, kNone, c->final_conv, B, 1, 0, nullptr, kNone, c->eps);
+    (void)H; (void)W;
 }
 
 void run_embed(sr3_ctx *c, const float *nl, int stride, int B) {
@@ -527,9 +568,9 @@ int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
     run_embed(c, c->d_nl + (t + 1), 0, B);
     run_unet_body(c, B, H, W);
     UpdateParams u;
-    u.state = c->x0; u.Cs = c->in_pad; u.C = c->cfg.out_channel;
+    u.state = c->x0; u.C = c->cfg.out_channel;
     u.xoff = c->cfg.in_channel - c->cfg.out_channel;
-    u.eps = c->eps; u.Ce = c->cfg.out_channel;
+    u.eps = c->eps;
     u.noise = noise_slab;
     u.a = c->s_a[t]; u.b = c->s_b[t]; u.c1 = c->s_c1[t]; u.c2 = c->s_c2[t];
     u.sigma = t > 0 ? expf(0.5f * c->s_lv[t]) : 0.f;
@@ -537,7 +578,7 @@ int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
     u.draw = (uint32_t)(c->T - t);
     u.frame = frame;
     c->pbegin(F_MISC);
-    launch_ddpm_update(u, B, H * W, c->stream);
+    launch_ddpm_update(u, B, c->stream);
     c->pend();
     return 0;
 }
@@ -663,12 +704,12 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     if (ensure_workspace(c, B, H, W)) return -1;
     c->sampling = false;
     c->pbegin(F_MISC);
-    launch_nchw_to_nhwc(x_dev, B, c->cfg.in_channel, H, W, c->x0, c->in_pad, 0, c->stream);
+    launch_nchw_to_nhwc(x_dev, B, c->cfg.in_channel, c->x0, 0, c->stream);
     c->pend();
     run_embed(c, noise_level_dev, 1, B);
     run_unet_body(c, B, H, W);
     c->pbegin(F_MISC);
-    launch_nhwc_to_nchw(c->eps, B, c->cfg.out_channel, H, W, c->cfg.out_channel, 0, out_dev, c->stream);
+    launch_nhwc_to_nchw(c->eps, 0, B, c->cfg.out_channel, out_dev, c->stream);
     c->pend();
     HIP_OK(hipGetLastError());
     return 0;
@@ -714,8 +755,8 @@ int sr3_sample_begin(sr3_ctx *c, const float *cond_dev, int B, int H, int W, con
     c->seed = seed;
     c->image_offset = image_offset;
     c->pbegin(F_MISC);
-    if (cond_dev) launch_nchw_to_nhwc(cond_dev, B, nc, H, W, c->x0, c->in_pad, 0, c->stream);
-    launch_init_state(c->x0, c->in_pad, nc, C, init_noise_dev, seed, image_offset, B, H * W, c->stream);
+    if (cond_dev) launch_nchw_to_nhwc(cond_dev, B, nc, c->x0, 0, c->stream);
+    launch_init_state(c->x0, nc, C, init_noise_dev, seed, image_offset, B, c->stream);
     c->pend();
     c->sampling = true;
     HIP_OK(hipGetLastError());
@@ -735,7 +776,7 @@ int sr3_sample_end(sr3_ctx *c, float *out_dev) {
     if (!c->sampling) return fail("sr3_sample_end before sr3_sample_begin");
     const int C = c->cfg.out_channel;
     c->pbegin(F_MISC);
-    launch_nhwc_to_nchw(c->x0, c->wB, C, c->wH, c->wW, c->in_pad, c->cfg.in_channel - C, out_dev, c->stream);
+    launch_nhwc_to_nchw(c->x0, c->cfg.in_channel - C, c->wB, C, out_dev, c->stream);
     c->pend();
     HIP_OK(hipGetLastError());
     return 0;
@@ -811,93 +852,107 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     if (!c || !in0_dev || !weight_host || !out_dev) return fail("sr3_op_conv2d: null argument");
     if ((C0 % 32) || (C1 % 32) || C0 <= 0 || C1 < 0) return fail("sr3_op_conv2d: C0=%d C1=%d must be multiples of 32", C0, C1);
     if (!(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (up2 & ~1)) return fail("sr3_op_conv2d: bad ks/stride/up2");
+    if ((gn_scale_dev == nullptr) != (gn_shift_dev == nullptr)) return fail("sr3_op_conv2d: scale and shift go together");
     HIP_OK(hipSetDevice(c->device));
+    if (!in1_dev) C1 = 0;
     const int Cin = C0 + C1, taps = ks * ks;
     std::vector<float> packed((size_t)taps * Cout * Cin);
     pack_conv_weight(weight_host, Cout, Cin, ks, Cin, packed.data());
-    float *dw = nullptr, *db = nullptr;
+    float *dw = nullptr, *db = nullptr, *act = nullptr;
     HIP_OK(hipMalloc(&dw, packed.size() * sizeof(float)));
     HIP_OK(hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     if (bias_host) {
         HIP_OK(hipMalloc(&db, (size_t)Cout * sizeof(float)));
         HIP_OK(hipMemcpy(db, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
     }
+    // the engine's own sequence: (GroupNorm apply | copy) + concat into a zero-bordered tensor, then conv
+    TDesc a; a.C = Cin; a.H = Hin; a.W = Win; a.pad = 1;
+    HIP_OK(hipMalloc(&act, a.floats(B) * sizeof(float)));
+    HIP_OK(hipMemsetAsync(act, 0, a.floats(B) * sizeof(float), c->stream));
+    a.p = act;
+    const TDesc i0 = unpadded(const_cast<float *>(in0_dev), C0, Hin, Win);
+    const TDesc i1 = in1_dev ? unpadded(const_cast<float *>(in1_dev), C1, Hin, Win) : kNone;
+    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, a, c->stream);
     const int pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
     ConvParams p;
-    p.in0 = in0_dev; p.in1 = in1_dev; p.C0 = C0; p.C1 = in1_dev ? C1 : 0;
-    p.B = B; p.Hin = Hin; p.Win = Win;
+    p.in0 = a; p.B = B;
     p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1;
     p.ks = ks; p.stride = stride; p.up2 = up2;
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
-    p.resid = resid_dev; p.gn_scale = gn_scale_dev; p.gn_shift = gn_shift_dev; p.swish = swish;
-    p.out = out_dev; p.Cout = Cout;
+    p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
+    if (resid_dev) p.resid = unpadded(const_cast<float *>(resid_dev), Cout, p.Hout, p.Wout);
     launch_conv(p, c->stream);
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipFree(dw));
+    HIP_OK(hipFree(act));
     if (db) HIP_OK(hipFree(db));
     HIP_OK(hipGetLastError());
     return 0;
 }
 
-// Times `iters` launches of one conv shape on scratch buffers (uninitialised weights are fine for
-// timing: f32 MFMA time does not depend on the data). mode 0 raw, 1 GN affine, 2 GN affine + Swish.
+// Times `iters` launches of one conv shape on scratch buffers (random contents; f32 MFMA time does
+// not depend on the data). `mode` > 0 additionally times the GroupNorm apply pass that precedes the
+// conv in the engine (1 affine, 2 affine + Swish) and reports it in *apply_ms.
 int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout, int ks, int stride, int up2,
-                   int mode, int with_resid, int with_chan_bias, int iters, float *avg_ms) {
+                   int mode, int with_resid, int with_chan_bias, int iters, float *avg_ms, float *apply_ms) {
     if (!c || !avg_ms) return fail("null argument");
     if ((C0 % 32) || (C1 % 32) || C0 <= 0) return fail("sr3_bench_conv: channels must be multiples of 32");
     HIP_OK(hipSetDevice(c->device));
     const int Cin = C0 + C1, pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
     const int Ho = (Hv + 2 * pad - ks) / stride + 1, Wo = (Wv + 2 * pad - ks) / stride + 1;
-    const size_t n_in0 = (size_t)B * Hin * Win * C0, n_in1 = (size_t)B * Hin * Win * C1;
-    const size_t n_out = (size_t)B * Ho * Wo * Cout, n_w = (size_t)ks * ks * Cout * Cin;
-    float *in0, *in1 = nullptr, *w, *bias, *out, *res = nullptr, *sc, *sh, *cb;
-    HIP_OK(hipMalloc(&in0, n_in0 * 4));
-    if (C1) HIP_OK(hipMalloc(&in1, n_in1 * 4));
+    TDesc i0, i1, act, out, res;
+    i0.C = C0; i1.C = C1; act.C = Cin; out.C = res.C = Cout;
+    i0.H = i1.H = act.H = Hin; i0.W = i1.W = act.W = Win; out.H = res.H = Ho; out.W = res.W = Wo;
+    i0.pad = i1.pad = act.pad = out.pad = res.pad = 1;
+    const size_t n_w = (size_t)ks * ks * Cout * Cin;
+    float *w, *bias, *sc, *sh, *cb;
+    HIP_OK(hipMalloc(&i0.p, i0.floats(B) * 4));
+    if (C1) HIP_OK(hipMalloc(&i1.p, i1.floats(B) * 4));
+    HIP_OK(hipMalloc(&act.p, act.floats(B) * 4));
+    HIP_OK(hipMalloc(&out.p, out.floats(B) * 4));
+    HIP_OK(hipMalloc(&res.p, res.floats(B) * 4));
     HIP_OK(hipMalloc(&w, n_w * 4));
     HIP_OK(hipMalloc(&bias, (size_t)Cout * 4));
-    HIP_OK(hipMalloc(&out, n_out * 4));
-    HIP_OK(hipMalloc(&res, n_out * 4));
     HIP_OK(hipMalloc(&sc, (size_t)B * Cin * 4));
     HIP_OK(hipMalloc(&sh, (size_t)B * Cin * 4));
     HIP_OK(hipMalloc(&cb, (size_t)B * Cout * 4));
-    // pseudo-random but finite contents (random data: MI355X guide rule 25)
-    launch_philox_normal(1, 0, 0, (int)std::min<size_t>(n_in0, 1u << 30), in0, c->stream);
-    if (C1) launch_philox_normal(2, 0, 0, (int)std::min<size_t>(n_in1, 1u << 30), in1, c->stream);
-    launch_philox_normal(3, 0, 0, (int)n_w, w, c->stream);
-    launch_philox_normal(4, 0, 0, Cout, bias, c->stream);
-    launch_philox_normal(5, 0, 0, (int)std::min<size_t>(n_out, 1u << 30), res, c->stream);
-    launch_philox_normal(6, 0, 0, B * Cin, sc, c->stream);
-    launch_philox_normal(7, 0, 0, B * Cin, sh, c->stream);
-    launch_philox_normal(8, 0, 0, B * Cout, cb, c->stream);
+    auto rnd = [&](float *q, size_t n, int seed) { launch_philox_normal(seed, 0, 0, (int)std::min<size_t>(n, 1u << 30), q, c->stream); };
+    rnd(i0.p, i0.floats(B), 1); if (C1) rnd(i1.p, i1.floats(B), 2);
+    rnd(act.p, act.floats(B), 9); rnd(w, n_w, 3); rnd(bias, Cout, 4); rnd(res.p, res.floats(B), 5);
+    rnd(sc, (size_t)B * Cin, 6); rnd(sh, (size_t)B * Cin, 7); rnd(cb, (size_t)B * Cout, 8);
     ConvParams p;
-    p.in0 = in0; p.in1 = in1; p.C0 = C0; p.C1 = C1; p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Ho; p.Wout = Wo;
+    p.in0 = act; p.B = B; p.Hout = Ho; p.Wout = Wo;
     p.ks = ks; p.stride = stride; p.up2 = up2; p.w = w; p.bias = bias;
     p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
-    p.resid = with_resid ? res : nullptr;
-    p.gn_scale = mode ? sc : nullptr; p.gn_shift = mode ? sh : nullptr; p.swish = mode == 2;
-    p.out = out; p.Cout = Cout;
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    if (with_resid) p.resid = res;
+    p.out = out;
+    hipEvent_t e0, e1, e2;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
     for (int i = 0; i < 2; ++i) launch_conv(p, c->stream);
     HIP_OK(hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) launch_conv(p, c->stream);
     HIP_OK(hipEventRecord(e1, c->stream));
-    HIP_OK(hipEventSynchronize(e1));
+    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, act, c->stream);
+    HIP_OK(hipEventRecord(e2, c->stream));
+    HIP_OK(hipEventSynchronize(e2));
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
-    HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
-    for (float *q : {in0, in1, w, bias, out, res, sc, sh, cb})
+    HIP_OK(hipEventElapsedTime(&ms, e1, e2));
+    if (apply_ms) *apply_ms = ms / iters;
+    HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1)); HIP_OK(hipEventDestroy(e2));
+    for (float *q : {i0.p, i1.p, act.p, out.p, res.p, w, bias, sc, sh, cb})
         if (q) HIP_OK(hipFree(q));
     HIP_OK(hipGetLastError());
     return 0;
 }
 
 int sr3_op_groupnorm_affine(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev, int C1, int B,
-                            int HW, int groups, const float *gamma_host, const float *beta_host,
+                            int H, int W, int groups, const float *gamma_host, const float *beta_host,
                             float *scale_dev, float *shift_dev) {
     if (!c || !in0_dev || !gamma_host || !beta_host || !scale_dev || !shift_dev) return fail("sr3_op_groupnorm_affine: null argument");
-    const int C = C0 + (in1_dev ? C1 : 0);
+    if (!in1_dev) C1 = 0;
+    const int C = C0 + C1;
     if (groups <= 0 || C % groups) return fail("groups=%d does not divide C=%d", groups, C);
     HIP_OK(hipSetDevice(c->device));
     float *dg = nullptr, *db = nullptr, *part = nullptr;
@@ -906,8 +961,9 @@ int sr3_op_groupnorm_affine(sr3_ctx *c, const float *in0_dev, int C0, const floa
     HIP_OK(hipMalloc(&part, gn_workspace_floats(B, groups) * sizeof(float)));
     HIP_OK(hipMemcpy(dg, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(db, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
-    launch_groupnorm_affine(in0_dev, C0, in1_dev, in1_dev ? C1 : 0, B, HW, groups, dg, db, 1e-5f, part,
-                            scale_dev, shift_dev, c->stream);
+    launch_groupnorm_affine(unpadded(const_cast<float *>(in0_dev), C0, H, W),
+                            in1_dev ? unpadded(const_cast<float *>(in1_dev), C1, H, W) : kNone, B, groups, dg, db,
+                            1e-5f, part, scale_dev, shift_dev, c->stream);
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipFree(dg)); HIP_OK(hipFree(db)); HIP_OK(hipFree(part));
     HIP_OK(hipGetLastError());
@@ -940,14 +996,14 @@ int sr3_op_noise_embed(sr3_ctx *c, const float *noise_level_dev, int B, float *t
 int sr3_op_nchw_to_nhwc(sr3_ctx *c, const float *in_dev, int B, int C, int H, int W, float *out_dev) {
     if (!c || !in_dev || !out_dev) return fail("null argument");
     HIP_OK(hipSetDevice(c->device));
-    launch_nchw_to_nhwc(in_dev, B, C, H, W, out_dev, C, 0, c->stream);
+    launch_nchw_to_nhwc(in_dev, B, C, unpadded(out_dev, C, H, W), 0, c->stream);
     HIP_OK(hipGetLastError());
     return 0;
 }
 int sr3_op_nhwc_to_nchw(sr3_ctx *c, const float *in_dev, int B, int C, int H, int W, float *out_dev) {
     if (!c || !in_dev || !out_dev) return fail("null argument");
     HIP_OK(hipSetDevice(c->device));
-    launch_nhwc_to_nchw(in_dev, B, C, H, W, C, 0, out_dev, c->stream);
+    launch_nhwc_to_nchw(unpadded(const_cast<float *>(in_dev), C, H, W), 0, B, C, out_dev, c->stream);
     HIP_OK(hipGetLastError());
     return 0;
 }

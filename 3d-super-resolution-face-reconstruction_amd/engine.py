@@ -190,10 +190,10 @@ class Engine:
 
     def bench_conv(self, B, H, W, C0, C1, Cout, ks=3, stride=1, up2=0, mode=2, resid=0, chan_bias=0,
                    iters=10) -> float:
-        ms = C.c_float()
+        ms, ams = C.c_float(), C.c_float()
         _lib.check(self.lib.sr3_bench_conv(self.ctx, B, H, W, C0, C1, Cout, ks, stride, up2, mode,
-                                           resid, chan_bias, iters, C.byref(ms)))
-        return ms.value
+                                           resid, chan_bias, iters, C.byref(ms), C.byref(ams)))
+        return ms.value, ams.value
 
     def profile_dump_csv(self, path: str):
         _lib.check(self.lib.sr3_profile_dump_csv(self.ctx, path.encode()))
@@ -235,7 +235,7 @@ class Engine:
         sc, sh = self.buffer(B * C), self.buffer(B * C)
         g, b = _host_f32(gamma), _host_f32(beta)
         _lib.check(self.lib.sr3_op_groupnorm_affine(
-            self.ctx, d0.ptr, C0, d1.ptr if d1 else None, C1, B, H * W, groups, g.ctypes.data,
+            self.ctx, d0.ptr, C0, d1.ptr if d1 else None, C1, B, H, W, groups, g.ctypes.data,
             b.ctypes.data, sc.ptr, sh.ptr))
         return sc.download((B, C)), sh.download((B, C))
 

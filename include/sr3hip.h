@@ -130,9 +130,11 @@ int sr3_profile_get(sr3_ctx *ctx, int family, double *total_ms, int64_t *launche
 int sr3_profile_dump_csv(sr3_ctx *ctx, const char *path);
 
 /* Kernel micro-benchmark: average ms of `iters` launches of one conv shape on scratch buffers
- * (mode 0 raw input, 1 GroupNorm affine, 2 affine + Swish). */
+ * and, in *apply_ms, of the
+ * GroupNorm apply pass that precedes it (mode 0 copy, 1 affine, 2 affine + Swish). */
 int sr3_bench_conv(sr3_ctx *ctx, int B, int Hin, int Win, int C0, int C1, int Cout, int ks, int stride,
-                   int up2, int mode, int with_resid, int with_chan_bias, int iters, float *avg_ms);
+                   int up2, int mode, int with_resid, int with_chan_bias, int iters, float *avg_ms,
+                   float *apply_ms);
 
 /* ---- single ops through the same kernels (parity tests call these) ------------------------ */
 
@@ -150,7 +152,7 @@ int sr3_op_conv2d(sr3_ctx *ctx, const float *in0_dev, int C0, const float *in1_d
 /* GroupNorm statistics folded with the affine: scale[b,c] = rstd*gamma[c],
  * shift[b,c] = beta[c] - mean*rstd*gamma[c]  (torch GroupNorm, eps 1e-5; unet.py:84,119). */
 int sr3_op_groupnorm_affine(sr3_ctx *ctx, const float *in0_dev, int C0, const float *in1_dev,
-                            int C1, int B, int HW, int groups, const float *gamma_host,
+                            int C1, int B, int H, int W, int groups, const float *gamma_host,
                             const float *beta_host, float *scale_dev, float *shift_dev);
 /* SelfAttention core (unet.py:132-139): qkv_dev [B, N, 3C] (q|k|v along the last axis) -> out
  * [B, N, C]; softmax(q.k / sqrt(C)) v, one head. */

@@ -37,9 +37,9 @@ if __name__ == "__main__":
     e = Engine(synth.tiny_unet_config(), 0)
     shapes = MAIN if not args.only else [MAIN[int(i)] for i in args.only.split(",")]
     for (B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb) in shapes:
-        ms = e.bench_conv(B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb, args.iters)
+        ms, ams = e.bench_conv(B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb, args.iters)
         Ho, Wo = (H * (2 if up else 1)) // st, (W * (2 if up else 1)) // st
         fl = 2.0 * B * Ho * Wo * Cout * ks * ks * (C0 + C1)
         print(f"B{B} {H}x{W} cin{C0}+{C1} cout{Cout} k{ks} s{st} u{up} mode{mode} res{rs} cb{cb}: "
-              f"{ms:8.4f} ms  {fl / ms / 1e9:7.2f} TFLOP/s", flush=True)
+              f"{ms:8.4f} ms  {fl / ms / 1e9:7.2f} TFLOP/s   (gn_apply {ams:.4f} ms)", flush=True)
     e.close()
