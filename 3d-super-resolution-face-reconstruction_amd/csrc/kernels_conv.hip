@@ -62,8 +62,9 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(512, 4) void conv_igemm_dma_f32(const ConvParams p) {
+// KS: 1 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into the gather
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2>
+__global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4) void conv_igemm_dma_f32(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_f32(const ConvParams p)
     }
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
-    const int taps = p.ks * p.ks;
-    const int nk = taps * (Cin / BK);
+    constexpr int TAPS = KS * KS;
+    const int nk = TAPS * (Cin / BK);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -113,14 +114,17 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_f32(const ConvParams p)
         }
         // DMA instruction i of this wave fills tile rows (4i + w) * 8 + (lane >> 3), lane & 7 is
         // the 16-B position inside the row; the source chunk is the swizzled one.
+        // Addresses are (uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset that is
+        // constant over the whole K loop), so a K-step costs the producers 8 DMA instructions
+        // and a few scalar adds — no vector ALU work (it would stall the co-resident MFMAs).
         const int rsub = lane >> 3;
-        const int schunk = (lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7);   // pos ^ ((row>>1)&7)
-        const int cpad = p.ks >> 1;
+        const unsigned schunk16 = (unsigned)(((lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7)) * 16);
+        constexpr int cpad = KS >> 1;
         const int tpad = p.in0.pad;
-        const int Wp = p.in0.Wp();
+        const int Hp = p.in0.Hp(), Wp = p.in0.Wp();
 
-        const float *a_p0[AR], *a_p1[AR];
-        int a_uy[AR], a_ux[AR];
+        unsigned vA0[AR], vA1[AR];            // UP2 == 0: offsets of the window origin (in0 / in1)
+        unsigned vY[UP2 ? AR : 1][3], vX[UP2 ? AR : 1][3];   // UP2 == 1: per-dy / per-dx parts
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
@@ -128,61 +132,61 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_f32(const ConvParams p)
             const int rem = m - n * HWo;
             const int oy = rem / p.Wout;
             const int ox = rem - oy * p.Wout;
-            a_uy[i] = oy * p.stride - cpad;
-            a_ux[i] = ox * p.stride - cpad;
-            const size_t img = (size_t)n * p.in0.Hp() * Wp;
-            a_p0[i] = p.in0.p + img * C0 + 4 * schunk;
-            a_p1[i] = C1 ? p.in1.p + img * C1 + 4 * schunk : a_p0[i];
+            if (UP2) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int sy = ((oy + d - 1) >> 1) + tpad, sx = ((ox + d - 1) >> 1) + tpad;
+                    vY[UP2 ? i : 0][d] = (unsigned)((n * Hp + sy) * Wp) * (unsigned)C0 * 4u;
+                    vX[UP2 ? i : 0][d] = (unsigned)sx * (unsigned)C0 * 4u + schunk16;
+                }
+            } else {
+                const unsigned pixbase = (unsigned)((n * Hp + oy * p.stride - cpad + tpad) * Wp +
+                                                    ox * p.stride - cpad + tpad);
+                vA0[i] = pixbase * (unsigned)C0 * 4u + schunk16;
+                vA1[i] = pixbase * (unsigned)C1 * 4u + schunk16;
+            }
         });
-        const float *b_ptr[BR];
+        unsigned vB[BR];
         static_for<BR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
-            b_ptr[i] = p.w + (size_t)n * Cin + 4 * schunk;
+            vB[i] = (unsigned)n * (unsigned)Cin * 4u + schunk16;
         });
-        const unsigned tapstride = (unsigned)Cout * (unsigned)Cin;
-        // (chunk, tap) iterator: tap inner, chunk outer; no division in the loop
-        int l_tap = 0, l_c0 = 0, l_dy = 0, l_dx = 0;
-
-#define SR3_DMA_TILE(BUF)                                                                          \
-    {                                                                                              \
-        float *Ad = smem + (BUF) * STAGE + w * 256;                                                \
-        float *Bd = smem + (BUF) * STAGE + BM * ROWF + w * 256;                                    \
-        const bool first_ = l_c0 < C0;                                                             \
-        const unsigned Cs_ = first_ ? C0 : C1;                                                     \
-        const unsigned cl_ = first_ ? l_c0 : l_c0 - C0;                                            \
-        static_for<AR>([&](auto ic) {                                                              \
-            constexpr int i = decltype(ic)::value;                                                 \
-            const int sy = ((a_uy[i] + l_dy) >> p.up2) + tpad;                                     \
-            const int sx = ((a_ux[i] + l_dx) >> p.up2) + tpad;                                     \
-            const unsigned pix = (unsigned)(__mul24(sy, Wp) + sx);                                 \
-            dma16((first_ ? a_p0[i] : a_p1[i]) + (__umul24(pix, Cs_) + cl_), Ad + i * 1024);       \
-        });                                                                                        \
-        const unsigned woff_ = (unsigned)l_tap * tapstride + (unsigned)l_c0;                       \
-        static_for<BR>([&](auto ic) {                                                              \
-            constexpr int i = decltype(ic)::value;                                                 \
-            dma16(b_ptr[i] + woff_, Bd + i * 1024);                                                \
-        });                                                                                        \
-        if (l_tap + 1 < taps) {                                                                    \
-            ++l_tap;                                                                               \
-            if (++l_dx == p.ks) { l_dx = 0; ++l_dy; }                                              \
-        } else {                                                                                   \
-            l_tap = 0; l_dx = 0; l_dy = 0; l_c0 += BK;                                             \
-        }                                                                                          \
-    }
+        const size_t tapstride = (size_t)Cout * Cin;   // floats between taps of the packed weights
 
         // step kt: consumers multiply tile kt out of stage kt&1 while tile kt+1 streams into the
         // other stage (free since the barrier that ended step kt-1); the barrier's implied
         // vmcnt(0) makes the DMA data visible before anybody reads it.
-        SR3_DMA_TILE(0)
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk && !(p.dbg & 1)) {
-                SR3_DMA_TILE((kt + 1) & 1)
-            }
-            __syncthreads();
+        int k = 0;
+        for (int c0 = 0; c0 < Cin; c0 += BK) {
+            const bool first = c0 < C0;
+            const int Cs = first ? C0 : C1;
+            const char *abase = reinterpret_cast<const char *>((first ? p.in0.p : p.in1.p) + (first ? c0 : c0 - C0));
+            const char *wbase = reinterpret_cast<const char *>(p.w + c0);
+            static_for<TAPS>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                constexpr int dy = tap / KS, dx = tap % KS;
+                float *Ad = smem + (k & 1) * STAGE + w * 256;
+                float *Bd = smem + (k & 1) * STAGE + BM * ROWF + w * 256;
+                if (!(p.dbg & 1) || k == 0) {
+                    const char *ab = UP2 ? abase : abase + (size_t)(dy * Wp + dx) * Cs * 4;
+                    if (p.dbg & 2) ab = reinterpret_cast<const char *>(p.in0.p);   // experiment: cache-hot source
+                    static_for<AR>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const unsigned vo = UP2 ? vY[UP2 ? i : 0][dy] + vX[UP2 ? i : 0][dx] : (first ? vA0[i] : vA1[i]);
+                        dma16(reinterpret_cast<const float *>(ab + vo), Ad + i * 1024);
+                    });
+                    const char *wb = (p.dbg & 2) ? reinterpret_cast<const char *>(p.w) : wbase + (size_t)tap * tapstride * 4;
+                    static_for<BR>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                    });
+                }
+                __syncthreads();
+                ++k;
+            });
         }
-#undef SR3_DMA_TILE
+        __syncthreads();
         return;
     }
 
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_f32(const ConvParams p)
 #undef SR3_FRAG_MMA
 
     // ---- epilogue: bias + FeatureWiseAffine channel bias + residual, stores into the padded
-    // output. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // output. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Processed 4 accumulator registers (4 consecutive rows) at a time to keep registers low.
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * WN + ni * 32 + li;
@@ -251,39 +256,40 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_f32(const ConvParams p)
         const float bs = p.bias ? p.bias[nc] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int rbase = wm * WM + mi * 32 + 4 * lh;
-            float add[16];
-            size_t o[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                add[r] = bs;
-                o[r] = (size_t)rowpix[rbase + (r & 3) + 8 * (r >> 2)] * Cout + nc;
-            }
-            if (p.resid.p != nullptr) {
+            for (int rq = 0; rq < 4; ++rq) {
+                const int rbase = wm * WM + mi * 32 + 8 * rq + 4 * lh;
+                float add[4];
+                unsigned o[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) add[r] += p.resid.p[o[r]];
-            }
-            if (p.chan_bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int img = rowimg[rbase + (r & 3) + 8 * (r >> 2)];
-                    add[r] += p.chan_bias[(size_t)img * p.chan_bias_stride + nc];
+                for (int j = 0; j < 4; ++j) {
+                    add[j] = bs;
+                    o[j] = (unsigned)rowpix[rbase + j] * (unsigned)Cout + (unsigned)nc;
                 }
-            }
+                if (p.resid.p != nullptr) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + rbase + (r & 3) + 8 * (r >> 2);
-                if (m < M && n < Cout) p.out.p[o[r]] = acc[mi][ni][r] + add[r];
+                    for (int j = 0; j < 4; ++j) add[j] += p.resid.p[o[j]];
+                }
+                if (p.chan_bias != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        add[j] += p.chan_bias[(size_t)rowimg[rbase + j] * p.chan_bias_stride + nc];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + rbase + j;
+                    if (m < M && n < Cout) p.out.p[o[j]] = acc[mi][ni][4 * rq + j] + add[j];
+                }
             }
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-void launch_cfg(const ConvParams &p, hipStream_t s) {
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2>
+void launch_inst(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t lds = ((size_t)2 * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
-    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN>;
+    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -294,8 +300,18 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), lds, s, p);
 }
 
+template <int BM, int BN, int WGM, int WGN>
+void launch_cfg(const ConvParams &p, hipStream_t s) {
+    if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0>(p, s);
+    else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1>(p, s);
+    else launch_inst<BM, BN, WGM, WGN, 3, 0>(p, s);
+}
+
 } // namespace
 
+// Preconditions (checked by the callers in sr3_api.hip): channels multiples of 32, 3x3 inputs
+// zero-bordered (pad 1), up2 only with ks 3 / stride 1 / single input, every tensor < 4 GiB
+// (32-bit byte offsets in the DMA addressing).
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     ConvParams p = p_in;
     if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
