@@ -30,6 +30,7 @@
 // Each lane reads 4 consecutive k per ds_read_b128 and feeds 4 MFMAs; lane half h supplies
 // k = 8kk + 4h + j to MFMA j of group kk for both operands.
 #include "sr3_internal.h"
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -40,6 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native vector (not HIP's float4 struct: struct copies through a register array become
 // memcpys via scratch memory)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -63,7 +65,8 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 }
 
 // KS: 1 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into the gather
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2>
+// PREC 0: exact f32 (v_mfma_f32_32x32x2_f32); PREC 1: split-f16, 3 x v_mfma_f32_32x32x16_f16
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
 __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4) void conv_igemm_dma_f32(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -202,16 +205,17 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // Fragment reads run one 8-k group ahead of the MFMAs (two register sets); the reads of the
-    // next tile's first group are issued right after the barrier and land under the last group's
-    // MFMAs, so the consumer never waits on LDS latency.
     const int swz = (li >> 1) & 7;          // == ((row >> 1) & 7) for every row this lane reads
     const float *Abase = smem + (wm * WM + li) * ROWF;
     const float *Bbase = smem + BM * ROWF + (wn * WN + li) * ROWF;
-    int koff[BK / 8];                       // float offset of chunk (2kk + lh) after swizzling
+    if constexpr (PREC == 0) {
+        // Fragment reads run one 8-k group ahead of the MFMAs (two register sets); the reads of
+        // the next tile's first group are issued right after the barrier and land under the last
+        // group's MFMAs, so the consumer never waits on LDS latency.
+        int koff[BK / 8];                   // float offset of chunk (2kk + lh) after swizzling
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) koff[kk] = (((2 * kk + lh) ^ swz) & 7) * 4;
-    f32x4 fa[2][MI], fb[2][NI];
+        for (int kk = 0; kk < BK / 8; ++kk) koff[kk] = (((2 * kk + lh) ^ swz) & 7) * 4;
+        f32x4 fa[2][MI], fb[2][NI];
 #define SR3_FRAG_READ(SET, CUR, KK)                                                                \
     {                                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) fa[SET][mi] =                            \
@@ -229,22 +233,72 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][mi].w, fb[SET][ni].w, acc[mi][ni], 0, 0, 0); \
         }                                                                                          \
     }
-    __syncthreads();
-    SR3_FRAG_READ(0, 0, 0)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        SR3_FRAG_READ(1, cur, 1)
-        SR3_FRAG_MMA(0)
-        SR3_FRAG_READ(0, cur, 2)
-        SR3_FRAG_MMA(1)
-        SR3_FRAG_READ(1, cur, 3)
-        SR3_FRAG_MMA(0)
-        __syncthreads();                       // every read of tile kt has been issued and waited
-        SR3_FRAG_READ(0, cur ^ 1, 0)           // next tile (stale data after the last one: unused)
-        SR3_FRAG_MMA(1)
-    }
+        __syncthreads();
+        SR3_FRAG_READ(0, 0, 0)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            SR3_FRAG_READ(1, cur, 1)
+            SR3_FRAG_MMA(0)
+            SR3_FRAG_READ(0, cur, 2)
+            SR3_FRAG_MMA(1)
+            SR3_FRAG_READ(1, cur, 3)
+            SR3_FRAG_MMA(0)
+            __syncthreads();                   // every read of tile kt has been issued and waited
+            SR3_FRAG_READ(0, cur ^ 1, 0)       // next tile (stale data after the last one: unused)
+            SR3_FRAG_MMA(1)
+        }
 #undef SR3_FRAG_READ
 #undef SR3_FRAG_MMA
+    } else {
+        // split-f16: a row is 32 hi halfs (16-B chunks 0..3) | 32 lo halfs (chunks 4..7). For the
+        // 16-wide K block s (0|1), lane half h holds k = 16s + 8h + j: hi chunk 2s+h, lo chunk
+        // 4+2s+h. Per 32x32 tile and K block: acc += Al*Bh + Ah*Bl + Ah*Bh (fp32 accumulate).
+        int hoff[2], loff[2];               // float offsets of the swizzled chunks
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            hoff[sb] = (((2 * sb + lh) ^ swz) & 7) * 4;
+            loff[sb] = (((4 + 2 * sb + lh) ^ swz) & 7) * 4;
+        }
+        h16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+#define SR3_FRAG_READ(SET, CUR, SB)                                                                \
+    {                                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
+            ah[SET][mi] = *reinterpret_cast<const h16x8 *>(Abase + (CUR) * STAGE + mi * 32 * ROWF + hoff[SB]); \
+            al[SET][mi] = *reinterpret_cast<const h16x8 *>(Abase + (CUR) * STAGE + mi * 32 * ROWF + loff[SB]); \
+        }                                                                                          \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
+            bh[SET][ni] = *reinterpret_cast<const h16x8 *>(Bbase + (CUR) * STAGE + ni * 32 * ROWF + hoff[SB]); \
+            bl[SET][ni] = *reinterpret_cast<const h16x8 *>(Bbase + (CUR) * STAGE + ni * 32 * ROWF + loff[SB]); \
+        }                                                                                          \
+    }
+#define SR3_FRAG_MMA(SET)                                                                          \
+    {                                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bl[SET][ni], acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+        }                                                                                          \
+    }
+        __syncthreads();
+        SR3_FRAG_READ(0, 0, 0)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            SR3_FRAG_READ(1, cur, 1)
+            SR3_FRAG_MMA(0)
+            __syncthreads();                   // every read of tile kt has been issued and waited
+            SR3_FRAG_READ(0, cur ^ 1, 0)
+            SR3_FRAG_MMA(1)
+        }
+#undef SR3_FRAG_READ
+#undef SR3_FRAG_MMA
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= p.w_unscale;
+    }
 
     // ---- epilogue: bias + FeatureWiseAffine channel bias + residual, stores into the padded
     // output. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -285,11 +339,11 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2>
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
 void launch_inst(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t lds = ((size_t)2 * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
-    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2>;
+    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2, PREC>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -302,9 +356,15 @@ void launch_inst(const ConvParams &p, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(const ConvParams &p, hipStream_t s) {
-    if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0>(p, s);
-    else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1>(p, s);
-    else launch_inst<BM, BN, WGM, WGN, 3, 0>(p, s);
+    if (p.prec == 0) {
+        if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0, 0>(p, s);
+        else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1, 0>(p, s);
+        else launch_inst<BM, BN, WGM, WGN, 3, 0, 0>(p, s);
+    } else {
+        if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0, 1>(p, s);
+        else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1, 1>(p, s);
+        else launch_inst<BM, BN, WGM, WGN, 3, 0, 1>(p, s);
+    }
 }
 
 } // namespace
@@ -339,6 +399,35 @@ void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, 
             for (int i = 0; i < Cin; ++i) d[i] = oihw[((size_t)o * Cin + i) * taps + t];
             for (int i = Cin; i < CinPad; ++i) d[i] = 0.f;
         }
+}
+
+// fp32 packed rows [rows][CinPad] -> per 32-channel chunk: 32 hi halfs | 32 lo halfs of w * 2^k,
+// k chosen so that max|w| * 2^k is in [1024, 2048): hi and lo are then normal fp16 numbers for all
+// but vanishing weights and w = (hi + lo) * 2^-k to ~2^-22 relative. Returns 2^-k.
+float split_conv_weight(const float *packed, size_t rows, int CinPad, float *dst) {
+    float mx = 0.f;
+    const size_t n = rows * (size_t)CinPad;
+    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(packed[i]));
+    int k = 0;
+    if (mx > 0.f) {
+        int e;
+        frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
+        k = 11 - e;              // mx * 2^k in [1024, 2048)
+    }
+    const float sc = ldexpf(1.0f, k);
+    _Float16 *d = reinterpret_cast<_Float16 *>(dst);
+    for (size_t r = 0; r < rows; ++r)
+        for (int c0 = 0; c0 < CinPad; c0 += 32) {
+            const float *src = packed + r * CinPad + c0;
+            _Float16 *o = d + (r * CinPad + c0) * 2;
+            for (int j = 0; j < 32; ++j) {
+                const float v = src[j] * sc;
+                const _Float16 hi = (_Float16)v;
+                o[j] = hi;
+                o[32 + j] = (_Float16)(v - (float)hi);
+            }
+        }
+    return ldexpf(1.0f, -k);
 }
 
 } // namespace sr3

@@ -7,6 +7,7 @@
 namespace sr3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 // =================================================================================================
 // GroupNorm statistics -> folded per-(image, channel) affine
@@ -153,7 +154,7 @@ __device__ __forceinline__ float swish_fast(float x) {
     return x * __frcp_rn(1.0f + __expf(-x));
 }
 
-template <int MODE>
+template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, const TDesc out) {
@@ -177,18 +178,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
     if (MODE == 2) {
         v.x = swish_fast(v.x); v.y = swish_fast(v.y); v.z = swish_fast(v.z); v.w = swish_fast(v.w);
     }
-    *reinterpret_cast<float4 *>(out.p + out.pix(n, y, x) * C + c) = v;
+    float *dst = out.p + out.pix(n, y, x) * C;
+    if (SPLIT) {
+        // chunk of 32 channels = 128 B: halfs [0,32) hi, [32,64) lo; x = hi + lo to ~2^-22 |x|
+        const float lim = 65504.0f;
+        float f[4] = {fminf(fmaxf(v.x, -lim), lim), fminf(fmaxf(v.y, -lim), lim),
+                      fminf(fmaxf(v.z, -lim), lim), fminf(fmaxf(v.w, -lim), lim)};
+        h16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = (_Float16)f[j];
+            lo[j] = (_Float16)(f[j] - (float)hi[j]);
+        }
+        _Float16 *hd = reinterpret_cast<_Float16 *>(dst + (c & ~31)) + (c & 31);
+        *reinterpret_cast<h16x4 *>(hd) = hi;
+        *reinterpret_cast<h16x4 *>(hd + 32) = lo;
+    } else {
+        *reinterpret_cast<float4 *>(dst + c) = v;
+    }
 }
 
 } // namespace
 
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, const TDesc &out, hipStream_t s) {
+                     int mode, int split, const TDesc &out, hipStream_t s) {
     const int items = out.W * (out.C >> 2);
     const dim3 grid((items + 255) / 256, B * out.H);
-    if (mode == 0) hipLaunchKernelGGL(gn_apply_kernel<0>, grid, dim3(256), 0, s, in0, in1, scale, shift, out);
-    else if (mode == 1) hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(256), 0, s, in0, in1, scale, shift, out);
-    else hipLaunchKernelGGL(gn_apply_kernel<2>, grid, dim3(256), 0, s, in0, in1, scale, shift, out);
+#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out)
+    if (split) {
+        if (mode == 0) SR3_GA(0, 1); else if (mode == 1) SR3_GA(1, 1); else SR3_GA(2, 1);
+    } else {
+        if (mode == 0) SR3_GA(0, 0); else if (mode == 1) SR3_GA(1, 0); else SR3_GA(2, 0);
+    }
+#undef SR3_GA
 }
 
 // =================================================================================================

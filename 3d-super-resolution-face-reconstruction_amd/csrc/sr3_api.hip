@@ -48,6 +48,8 @@ struct Param {
     ParamKind kind = P_PLAIN;
     int cout = 0, cin = 0, ks = 0, cin_pad = 0;  // P_CONV
     float *dev = nullptr;                        // device storage (kernel layout)
+    float *dev_split = nullptr;                  // P_CONV: split-f16 copy (prec 1), same size
+    float w_unscale = 1.0f;
     size_t dev_floats = 0;
     bool owns = true;                            // false: a view into a concatenated buffer
     bool loaded = false;
@@ -73,6 +75,7 @@ struct Module {
     TDesc out;      // module output (zero-bordered)
     TDesc rb_out;   // ResBlock output before attention (== out if no attention)
     TDesc act1, act2, h1;   // activated conv inputs and the block1 output (per-shape buffers)
+    TDesc up_in;            // M_UP: split-f16 copy of the input (prec 1)
     int oc = 0, oh = 0, ow = 0;
 };
 
@@ -98,6 +101,7 @@ struct sr3_ctx {
     int in_pad = 0;     // in_channel padded to 32
     int c_max = 0;      // widest GroupNorm input
     uint64_t weight_bytes = 0;
+    int prec = 0;       // 0 exact f32 MFMA, 1 split-f16 (f16x3) for the 3x3 / activated-input convs
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -324,6 +328,10 @@ int alloc_weights(sr3_ctx *c) {
         p.dev_floats = n;
         HIP_OK(hipMalloc(&p.dev, n * sizeof(float)));
         c->weight_bytes += n * sizeof(float);
+        if (p.kind == P_CONV) {
+            HIP_OK(hipMalloc(&p.dev_split, n * sizeof(float)));
+            c->weight_bytes += n * sizeof(float);
+        }
     }
     return 0;
 }
@@ -380,7 +388,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         int oc;
         if (m.kind == M_CONV_IN) { oc = m.conv.cout; }
         else if (m.kind == M_DOWN) { oc = m.conv.cout; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
-        else if (m.kind == M_UP) { oc = m.conv.cout; h *= 2; w *= 2; }
+        else if (m.kind == M_UP) { oc = m.conv.cout; a1_off[i] = acts.get(cv, B, m.conv.cin, h, w); a2_off[i] = h * 65536 + w; h *= 2; w *= 2; }
         else {
             oc = m.rb.cout;
             a1_off[i] = acts.get(cv, B, m.rb.cin, h, w);
@@ -426,6 +434,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         Module &m = c->mods[i];
         m.out = desc(out_off[i], m.oc, m.oh, m.ow, 1);
         m.rb_out = desc(rb_off[i], m.oc, m.oh, m.ow, 1);
+        if (m.kind == M_UP) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);
         if (m.kind == M_RES) {
             m.act1 = desc(a1_off[i], m.rb.cin, m.oh, m.ow, 1);
             m.act2 = desc(a2_off[i], m.oc, m.oh, m.ow, 1);
@@ -452,16 +461,19 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
     c->pbegin(F_GN);
     launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
                             c->gpart, c->gscale, c->gshift, c->stream);
-    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, act, c->stream);
+    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream);
     c->pend();
 }
 
+// `activated`: the input was written by launch_gn_apply and is in the context's precision format
 void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int B, int stride, int up2,
-              const float *chan_bias, const TDesc &resid, const TDesc &out) {
+              const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
-    p.w = c->params[cv.w].dev;
+    p.prec = activated ? c->prec : 0;
+    p.w = p.prec ? c->params[cv.w].dev_split : c->params[cv.w].dev;
+    p.w_unscale = c->params[cv.w].w_unscale;
     p.bias = cv.b >= 0 ? c->params[cv.b].dev : nullptr;
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
     p.resid = resid; p.out = out;
@@ -469,8 +481,8 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     launch_conv(p, c->stream);
     if (c->prof) {
         char tag[160];
-        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d", cv.ks, stride, up2, out.H,
-                 out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0);
+        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d prec%d", cv.ks, stride, up2, out.H,
+                 out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, p.prec);
         c->pend(2.0 * (double)B * out.H * out.W * cv.cout * (double)(cv.ks * cv.ks) * cv.cin, tag);
     }
 }
@@ -484,7 +496,7 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const TDesc &skip, int B) {
     const ResBlock &rb = m.rb;
     const int h = m.oh, w = m.ow;
     run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1);
-    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1);
+    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true);
     TDesc resid = x;
     if (rb.has_res) {
         TDesc r = m.rb_out; r.p = c->rbuf;          // same geometry as the block output
@@ -492,11 +504,11 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const TDesc &skip, int B) {
         resid = r;
     }
     run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2);
-    run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, resid, m.rb_out);
+    run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, resid, m.rb_out, true);
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2);
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
-        run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv);
+        run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv, true);
         c->pbegin(F_ATTN);
         const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
         c->pend(fl);
@@ -520,7 +532,14 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
             run_conv(c, cur, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out);
             break;
         case M_UP:
-            run_conv(c, cur, kNone, m.conv, B, 1, 1, nullptr, kNone, m.out);
+            if (c->prec) {   // the raw module output is re-stored in split-f16 form for the fast conv
+                c->pbegin(F_GN);
+                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
+                c->pend();
+                run_conv(c, m.up_in, kNone, m.conv, B, 1, 1, nullptr, kNone, m.out, true);
+            } else {
+                run_conv(c, cur, kNone, m.conv, B, 1, 1, nullptr, kNone, m.out);
+            }
             break;
         case M_RES:
             if (is_up_path) {
@@ -536,7 +555,7 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
         if (i < c->n_downs) feats.push_back(i);
     }
     run_gn_act(c, cur, kNone, c->final_gn, B, 2, c->final_act);
-    run_conv(c, c->final_act, kNone, c->final_conv, B, 1, 0, nullptr, kNone, c->eps);
+    run_conv(c, c->final_act, kNone, c->final_conv, B, 1, 0, nullptr, kNone, c->eps, true);
     (void)H; (void)W;
 }
 
@@ -623,8 +642,10 @@ void sr3_destroy(sr3_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &p : c->params)
+    for (auto &p : c->params) {
         if (p.owns && p.dev) (void)hipFree(p.dev);
+        if (p.dev_split) (void)hipFree(p.dev_split);
+    }
     if (c->nfw) (void)hipFree(c->nfw);
     if (c->nfb) (void)hipFree(c->nfb);
     if (c->arena) (void)hipFree(c->arena);
@@ -639,6 +660,13 @@ int sr3_set_stream(sr3_ctx *c, void *hip_stream) {
     if (!c) return fail("null context");
     c->pflush();
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return 0;
+}
+
+int sr3_set_precision(sr3_ctx *c, int prec) {
+    if (!c) return fail("null context");
+    if (prec != 0 && prec != 1) return fail("precision %d unknown (0 = f32 exact, 1 = split-f16)", prec);
+    c->prec = prec;
     return 0;
 }
 
@@ -679,6 +707,9 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
             std::vector<float> packed(p.dev_floats);
             pack_conv_weight(host, p.cout, p.cin, p.ks, p.cin_pad, packed.data());
             HIP_OK(hipMemcpy(p.dev, packed.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+            std::vector<float> sp(p.dev_floats);
+            p.w_unscale = split_conv_weight(packed.data(), (size_t)p.ks * p.ks * p.cout, p.cin_pad, sp.data());
+            HIP_OK(hipMemcpy(p.dev_split, sp.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
         } else {
             HIP_OK(hipMemcpy(p.dev, host, p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -858,6 +889,12 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     const int Cin = C0 + C1, taps = ks * ks;
     std::vector<float> packed((size_t)taps * Cout * Cin);
     pack_conv_weight(weight_host, Cout, Cin, ks, Cin, packed.data());
+    float w_unscale = 1.0f;
+    if (c->prec) {
+        std::vector<float> sp(packed.size());
+        w_unscale = split_conv_weight(packed.data(), (size_t)taps * Cout, Cin, sp.data());
+        packed.swap(sp);
+    }
     float *dw = nullptr, *db = nullptr, *act = nullptr;
     HIP_OK(hipMalloc(&dw, packed.size() * sizeof(float)));
     HIP_OK(hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -872,12 +909,13 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     a.p = act;
     const TDesc i0 = unpadded(const_cast<float *>(in0_dev), C0, Hin, Win);
     const TDesc i1 = in1_dev ? unpadded(const_cast<float *>(in1_dev), C1, Hin, Win) : kNone;
-    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, a, c->stream);
+    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, c->prec, a, c->stream);
     const int pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
     ConvParams p;
     p.in0 = a; p.B = B;
     p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1;
     p.ks = ks; p.stride = stride; p.up2 = up2;
+    p.prec = c->prec; p.w_unscale = w_unscale;
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
     p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
     if (resid_dev) p.resid = unpadded(const_cast<float *>(resid_dev), Cout, p.Hout, p.Wout);
@@ -923,6 +961,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     ConvParams p;
     p.in0 = act; p.B = B; p.Hout = Ho; p.Wout = Wo;
     p.ks = ks; p.stride = stride; p.up2 = up2; p.w = w; p.bias = bias;
+    p.prec = c->prec;
     p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
     if (with_resid) p.resid = res;
     p.out = out;
@@ -932,7 +971,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     HIP_OK(hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) launch_conv(p, c->stream);
     HIP_OK(hipEventRecord(e1, c->stream));
-    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, act, c->stream);
+    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, c->prec, act, c->stream);
     HIP_OK(hipEventRecord(e2, c->stream));
     HIP_OK(hipEventSynchronize(e2));
     float ms = 0.f;

@@ -35,11 +35,20 @@ struct ConvParams {
     int chan_bias_stride = 0;
     TDesc resid;            // p == nullptr if none; same geometry as out
     TDesc out;              // C = Cout
+    // prec 0: exact f32 MFMA; inputs / weights are fp32.
+    // prec 1: split-f16 ("f16x3"): every 32-channel chunk of the inputs and of the packed weights is
+    //         stored as 32 hi halfs | 32 lo halfs (x = hi + lo to ~2^-22), the product is
+    //         hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; weights are
+    //         pre-scaled by 2^k (w_unscale = 2^-k is applied to the accumulator in the epilogue).
+    int prec = 0;
+    float w_unscale = 1.0f;
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
 void launch_conv(const ConvParams &p, hipStream_t s);
 // host helper: OIHW -> [tap][Cout][CinPad] (zero pad input channels up to CinPad)
 void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, float *dst);
+// host helper: fp32 packed weights -> split-f16 layout (same byte size), returns the unscale factor
+float split_conv_weight(const float *packed, size_t rows, int CinPad, float *dst);
 
 // ---- GroupNorm (kernels_misc.hip) -------------------------------------------------------------
 // statistics over the virtual concatenation in0 ‖ in1 -> folded affine scale/shift [B][C]
@@ -48,9 +57,10 @@ void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int grou
                              const float *beta, float eps, float *part, float *scale, float *shift,
                              hipStream_t s);
 // out[n,y,x,:] = act(concat(in0,in1)[n,y,x,:] * scale[n,:] + shift[n,:]); mode 0 copy, 1 affine,
-// 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only.
+// 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only. split != 0 stores every
+// 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format).
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, const TDesc &out, hipStream_t s);
+                     int mode, int split, const TDesc &out, hipStream_t s);
 
 // ---- attention core ----------------------------------------------------------------------------
 double launch_attention(const float *qkv, int B, int N, int C, float *out, hipStream_t s);

@@ -99,6 +99,13 @@ class Engine:
     def set_stream(self, stream_handle: Optional[int]):
         _lib.check(self.lib.sr3_set_stream(self.ctx, stream_handle or None))
 
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def set_precision(self, name: str):
+        """'f32': exact fp32 MFMA (default). 'f16x3': split-f16 operands, fp32-equivalent accuracy."""
+        _lib.check(self.lib.sr3_set_precision(self.ctx, self.PRECISIONS[name]))
+        self.precision = name
+
     def synchronize(self):
         _lib.check(self.lib.sr3_synchronize(self.ctx))
 

@@ -34,7 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = "3d-super-resolution-face-reconstruction_amd"
 sys.path.insert(0, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
+# MI355X_MICROARCH.md, dense peaks: v_mfma_f32_32x32x2_f32 (= f32 vector peak) and f16/bf16 MFMA
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
+DTYPE = {"f32": "f32", "f16x3": "f16x3-split (hi+lo fp16 operands, 3 MFMA per product, fp32 accumulate)"}
 
 
 def parse():
@@ -47,6 +49,9 @@ def parse():
     ap.add_argument("--lres", type=int, default=16)
     ap.add_argument("--T", type=int, default=1000, help="diffusion steps per image (BASELINE configs[1]: 1000)")
     ap.add_argument("--image-size", type=int, default=224, help="UNet image_size key: 224 = yml-literal, 128 = 6 attention modules")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="conv arithmetic: exact f32 MFMA, or split-f16 (fp32-equivalent accuracy, default)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the secondary measurement of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -89,6 +94,17 @@ def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
     return base, parity
 
 
+def pmc_traffic(precision):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC summary (tools/pmc_summary.py),
+    corrected as MI355X_MICROARCH.md prescribes; None if no summary for this precision."""
+    path = os.path.join(ROOT, "profiles", f"pmc_latest_{precision}.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm"]["conv_igemm"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     import torch
@@ -114,6 +130,7 @@ def main():
     eng = Engine(cfg, local)
     eng.load_state_dict(sd)
     eng.set_schedule(schedule.schedule_buffers(sched_opt))
+    eng.set_precision(args.precision)
     stream = torch.cuda.current_stream(local)
     eng.set_stream(stream.cuda_stream)
 
@@ -166,29 +183,52 @@ def main():
         avg_ms = conv["ms"] / n
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         total_ms = sum(v["ms"] for v in prof.values())
+        peak = PEAK_TFLOPS[args.precision]
         roof = {
-            "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": "conv_igemm_f32<BM,BN> (all tile shapes)", "launches_per_step": n / K,
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": pmc_traffic(args.precision),
+            "note": ("achieved = algorithmic conv FLOPs / HIP-event time; in f16x3 every algorithmic MAC costs 3 "
+                     "MFMA MACs, so matrix-pipe utilisation is 3x frac") if args.precision == "f16x3" else
+                    "achieved = algorithmic conv FLOPs / HIP-event time on the exact-f32 MFMA",
+            "kernel": "conv_igemm_dma_f32<BM,BN,...> (all tile shapes)", "launches_per_step": n / K,
             "avg_launch_ms": avg_ms, "flop_per_launch": conv["flops"] / n,
             "family_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
-            "whole_step_frac": (B * graph.flops_per_image(cfg, r, r) / sec_per_step / 1e12) / F32_MFMA_PEAK_TFLOPS,
+            "whole_step_frac": (B * graph.flops_per_image(cfg, r, r) / sec_per_step / 1e12) / peak,
             "event_timed_step_ms": total_ms / K,
         }
 
+    alt = None
+    if rank == 0 and not args.no_alt:
+        other = "f32" if args.precision == "f16x3" else "f16x3"
+        eng.set_precision(other)
+        t_a = run_steps(max(1, W), t_next)
+        torch.cuda.synchronize()
+        ta0 = time.perf_counter()
+        t_a = run_steps(K, t_a)
+        torch.cuda.synchronize()
+        sa = (time.perf_counter() - ta0) / K
+        eng.profile_reset(); eng.profile_enable(True)
+        run_steps(min(K, 5), t_a)
+        pa = eng.profile_get()["conv_igemm"]
+        eng.profile_enable(False)
+        alt = {"precision": other, "ms_per_step": sa * 1e3, "img_per_s_1gpu": B / (T * sa),
+               "conv_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] else 0.0,
+               "conv_frac_of_peak": (pa["flops"] / (pa["ms"] * 1e-3) / 1e12) / PEAK_TFLOPS[other] if pa["ms"] else 0.0}
+        eng.set_precision(args.precision)
     if rank == 0:
         res = {
             "metric": "SR images/sec (full p_sample_loop, 16->128)",
             "value": world * B / (T * sec_per_step), "unit": "img/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"sr_sr3_VGGF2_{args.lres}_{r} p_sample_loop, yml UNet image_size={args.image_size}",
                        "batch_per_gpu": B, "global_batch": B * world, "T": T,
                        "gflop_per_image_step": graph.flops_per_image(cfg, r, r) / 1e9,
                        "step": "one p_sample step (UNet forward + DDPM update) over the per-GPU batch",
                        "parallelism": f"batch-sharded x{world}, one all-gather at the end"},
             "roofline": roof,
+            "alt_precision": alt,
         }
         if not args.no_cpu_baseline and world == 1:
             base, parity = cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth)

@@ -58,6 +58,11 @@ const char *sr3_last_error(void);
 /* work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) */
 int sr3_set_stream(sr3_ctx *ctx, void *hip_stream);
 int sr3_synchronize(sr3_ctx *ctx);
+/* Arithmetic of the convolutions: 0 = exact f32 on v_mfma_f32_32x32x2_f32 (default; bit-faithful
+ * fp32 products), 1 = split-f16 ("f16x3"): operands stored as hi + lo halfs, three
+ * v_mfma_f32_32x32x16_f16 per product with fp32 accumulation — fp32-equivalent accuracy (error of
+ * the same size as fp32 accumulation itself) at ~5x the matrix rate. */
+int sr3_set_precision(sr3_ctx *ctx, int prec);
 
 /* ---- weights: reference state_dict names and layouts ------------------------------------- */
 

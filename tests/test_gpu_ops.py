@@ -38,8 +38,13 @@ CONV_CASES = [
 ]
 
 
+PRECISIONS = ["f32", "f16x3"]   # exact fp32 MFMA | split-f16 (hi+lo operands, fp32 accumulate)
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d(eng, case):
+def test_conv2d(eng, case, prec):
+    eng.set_precision(prec)
     B, H, W, C0, C1, Cout, ks, stride, up2 = case
     rs = np.random.RandomState(hash(case) & 0xFFFF)
     x0 = _rand(rs, B, H, W, C0)
@@ -51,13 +56,16 @@ def test_conv2d(eng, case):
     if up2:
         xin = oracle.upsample_nearest2(xin)
     want = oracle.conv2d(xin, w, b, stride=stride)
+    eng.set_precision("f32")
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=0)
 
 
-def test_conv2d_fused_prologue_epilogue(eng):
-    """GroupNorm+Swish folded into the A-tile fill, FeatureWiseAffine bias and residual in the
-    epilogue == Block + noise_func + residual of ResnetBlock.forward (unet.py:105-110)."""
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_conv2d_fused_prologue_epilogue(eng, prec):
+    """GroupNorm apply + Swish pass, conv, FeatureWiseAffine bias and residual in the epilogue ==
+    Block + noise_func + residual of ResnetBlock.forward (unet.py:105-110)."""
+    eng.set_precision(prec)
     rs = np.random.RandomState(5)
     B, H, W, C, Cout = 3, 16, 16, 64, 64
     x = _rand(rs, B, H, W, C) * 2 + 0.5
@@ -68,7 +76,22 @@ def test_conv2d_fused_prologue_epilogue(eng):
     got = eng.op_conv2d(x, w, b, gn_scale=sc, gn_shift=sh, swish=True, chan_bias=cb, resid=resid)
     want = oracle.conv2d(oracle.swish(oracle.group_norm(x, gamma, beta, 32)), w, b)
     want = want + cb[:, None, None, :] + resid
+    eng.set_precision("f32")
     np.testing.assert_allclose(got, want, atol=3e-5, rtol=0)
+
+
+def test_conv2d_f16x3_wide_dynamic_range(eng):
+    """split-f16 keeps fp32-level accuracy for tiny and large operands (weights are pre-scaled by
+    2^k, activations are bounded by GroupNorm in the network; here up to +-3e3)."""
+    rs = np.random.RandomState(9)
+    x = (_rand(rs, 2, 16, 16, 64) * np.exp(rs.uniform(-12, 8, (2, 16, 16, 64)))).astype(np.float32)
+    w = (_rand(rs, 64, 64, 3, 3) * 1e-3).astype(np.float32)
+    eng.set_precision("f16x3")
+    got = eng.op_conv2d(x, w, None)
+    eng.set_precision("f32")
+    want = oracle.conv2d(x.astype(np.float64), w.astype(np.float64))
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 2e-6 * scale
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, 32, 0), (2, 16, 16, 64, 32), (3, 8, 8, 512, 256),

@@ -14,21 +14,26 @@ metrics = pkg("metrics")
 BAR = 1e-3
 
 
-def _engine(cfg, seed, sched_opt):
+PRECISIONS = ["f32", "f16x3"]
+
+
+def _engine(cfg, seed, sched_opt, prec="f32"):
     e = pkg("engine").Engine(cfg, 0)
     e.load_state_dict(synth.synth_state_dict(cfg, seed))
+    e.set_precision(prec)
     with np.errstate(divide="ignore", invalid="ignore"):
         e.set_schedule(schedule.schedule_buffers(sched_opt))
     return e
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", ["sampler_tiny.npz", "sampler_uncond_tiny.npz", "sampler_cfg1_8_16.npz"])
-def test_sampler_golden(name):
+def test_sampler_golden(name, prec):
     g = load_golden(name)
     m = g["meta"]
     cfg = cfg_from_meta(m)
     B, r, T = m["B"], m["r"], m["schedule"]["n_timestep"]
-    e = _engine(cfg, m["seed"], m["schedule"])
+    e = _engine(cfg, m["seed"], m["schedule"], prec)
     noise = synth.synth_noise(T, B, 3, r, r, m["seed"])
     cond = g["cond"] if m["conditional"] else None
     final, frames = e.sample_np(cond, noise=noise, frames=True, shape=(B, 3, r, r))
@@ -36,7 +41,7 @@ def test_sampler_golden(name):
     assert nf == len(schedule.frame_steps(T)) == (g["ret_img"].shape[0] // B - 1)
     ref_frames = g["ret_img"][B:].reshape(nf, B, 3, r, r)
     err = np.abs(frames - ref_frames).reshape(nf, -1).max(1)
-    print(f"{name}: per-frame max abs err {np.array2string(err, precision=2)}; "
+    print(f"{name} [{prec}]: per-frame max abs err {np.array2string(err, precision=2)}; "
           f"PSNR final {metrics.batch_psnr(final, ref_frames[-1]):.1f} dB")
     assert err.max() <= BAR
     np.testing.assert_array_equal(final, frames[-1])

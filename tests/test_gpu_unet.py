@@ -11,10 +11,14 @@ synth = pkg("synth")
 TOL = 1e-4   # well inside the 1e-3 bar
 
 
-def _engine(cfg, seed):
+PRECISIONS = ["f32", "f16x3"]
+
+
+def _engine(cfg, seed, prec="f32"):
     e = pkg("engine").Engine(cfg, 0)
     e.load_state_dict(synth.synth_state_dict(cfg, seed))
     assert e.weights_missing() == 0
+    e.set_precision(prec)
     return e
 
 
@@ -34,15 +38,16 @@ def test_param_inventory_matches_reference_state_dict():
     e.close()
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", ["unet_tiny.npz", "unet_yml224_r16.npz", "unet_yml128_r32.npz",
                                   "unet_yml224_r128.npz"])
-def test_unet_forward_golden(name):
+def test_unet_forward_golden(name, prec):
     g = load_golden(name)
     cfg = cfg_from_meta(g["meta"])
-    e = _engine(cfg, g["meta"]["seed"])
+    e = _engine(cfg, g["meta"]["seed"], prec)
     eps = e.unet_forward_np(g["x"], g["noise_level"])
     err = np.abs(eps - g["eps"]).max()
-    print(f"{name}: max abs err vs reference {err:.3e}")
+    print(f"{name} [{prec}]: max abs err vs reference {err:.3e}")
     assert err < TOL
     # a second call on the same context reuses the workspace and must reproduce itself exactly
     np.testing.assert_array_equal(e.unet_forward_np(g["x"], g["noise_level"]), eps)

@@ -31,10 +31,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=str, default="", help="comma list of shape indices")
+    ap.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3"])
     args = ap.parse_args()
     synth = importlib.import_module(PKG + ".synth")
     Engine = importlib.import_module(PKG + ".engine").Engine
     e = Engine(synth.tiny_unet_config(), 0)
+    e.set_precision(args.precision)
     shapes = MAIN if not args.only else [MAIN[int(i)] for i in args.only.split(",")]
     for (B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb) in shapes:
         ms, ams = e.bench_conv(B, H, W, C0, C1, Cout, ks, st, up, mode, rs, cb, args.iters)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 CSV output of `bench.py` runs into profiles/ (development tool).
+
+    python tools/pmc_summary.py gpurun_out profiles/r01
+
+Reads gpurun_out/p_stats (kernel-trace --stats), p_fetch (--pmc FETCH_SIZE), p_write
+(--pmc WRITE_SIZE), p_sq (SQ counters) and writes <prefix>_kernel_stats.csv and
+<prefix>_pmc_summary.json. HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE
+are in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read, so reads = 2*FETCH_SIZE*1024.
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    for key, fam in (("conv_igemm", "conv_igemm"), ("gn_partial", "gn_stats"), ("gn_finalize", "gn_stats"),
+                     ("gn_apply", "gn_apply"), ("attention", "attention"), ("noise_embed", "embed"),
+                     ("ddpm_update", "update")):
+        if key in name:
+            return fam
+    return "other"
+
+
+def load(d, pat):
+    f = glob.glob(f"{d}/*/*{pat}")
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def main(src, prefix):
+    out = {}
+    ks = glob.glob(f"{src}/p_stats/*/*kernel_stats.csv")
+    if ks:
+        shutil.copy(ks[0], prefix + "_kernel_stats.csv")
+    trace = load(f"{src}/p_stats", "kernel_trace.csv")
+    dur = defaultdict(lambda: [0, 0.0])
+    for r in trace:
+        fam = family(r["Kernel_Name"])
+        dur[fam][0] += 1
+        dur[fam][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    out["kernel_trace_ms"] = {k: {"launches": v[0], "total_ms": v[1], "avg_ms": v[1] / v[0]} for k, v in dur.items()}
+    for tag, cname in (("p_fetch", "FETCH_SIZE"), ("p_write", "WRITE_SIZE")):
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in load(f"{src}/{tag}", "counter_collection.csv"):
+            if r["Counter_Name"] == cname:
+                fam = family(r["Kernel_Name"])
+                acc[fam][0] += 1
+                acc[fam][1] += float(r["Counter_Value"])
+        out[cname + "_KiB"] = {k: {"launches": v[0], "sum": v[1]} for k, v in acc.items()}
+    hbm = {}
+    for fam in out.get("FETCH_SIZE_KiB", {}):
+        f, w = out["FETCH_SIZE_KiB"][fam], out.get("WRITE_SIZE_KiB", {}).get(fam, {"sum": 0, "launches": 1})
+        n = max(1, f["launches"])
+        hbm[fam] = {"read_bytes_per_launch": 2 * f["sum"] * 1024 / n, "write_bytes_per_launch": w["sum"] * 1024 / max(1, w["launches"])}
+        hbm[fam]["bytes_per_launch"] = hbm[fam]["read_bytes_per_launch"] + hbm[fam]["write_bytes_per_launch"]
+    out["hbm"] = hbm
+    sq = defaultdict(lambda: defaultdict(float))
+    for r in load(f"{src}/p_sq", "counter_collection.csv"):
+        sq[family(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    for fam, c in sq.items():
+        if c.get("GRBM_GUI_ACTIVE"):
+            c["mfma_busy_frac_of_simd_cycles"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)
+    out["sq"] = {k: dict(v) for k, v in sq.items()}
+    json.dump(out, open(prefix + "_pmc_summary.json", "w"), indent=1)
+    print(json.dumps({"hbm": hbm, "mfma_busy": {k: v.get("mfma_busy_frac_of_simd_cycles") for k, v in out["sq"].items()},
+                      "trace": out["kernel_trace_ms"]}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
