@@ -7,56 +7,43 @@
 namespace sr3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 // =================================================================================================
 // GroupNorm statistics -> folded per-(image, channel) affine
 //   reference: nn.GroupNorm(groups, C) inside Block / SelfAttention, unet.py:84,119 (eps 1e-5,
 //   biased variance over (C/groups)*H*W, groups of contiguous channels of the concatenated input).
-// Kernel 1 streams each image slice with lanes along the channel axis (coalesced 256-B rows),
-// keeps a Welford (count, mean, M2) per thread and merges them with Chan's formula: no
-// E[x^2]-mean^2 cancellation. Kernel 2 merges the slices and writes scale/shift.
+// Kernel 1 streams each image slice with 16-byte loads (a thread owns one channel quad, lanes run
+// along the channel axis = coalesced rows) and accumulates sum and sum-of-squares per channel in
+// fp64 (E[x^2]-mean^2 is then safe: 2^-53 relative), writes per-(image, slice, channel) partials.
+// Kernel 2 adds the slices and the channels of each group (any group size, groups may straddle the
+// x/skip boundary of a concatenation) and writes scale = rstd*gamma, shift = beta - mean*scale.
+// Deterministic: no atomics.
 // =================================================================================================
 namespace {
 
 constexpr int GN_MAX_SLICES = 64;
 
-struct Wf { float n, mean, m2; };
-
-__device__ __forceinline__ void wf_push(Wf &s, float x) {
-    s.n += 1.0f;
-    const float d = x - s.mean;
-    s.mean += d * __frcp_rn(s.n);
-    s.m2 = fmaf(d, x - s.mean, s.m2);
-}
-__device__ __forceinline__ void wf_merge(Wf &a, const Wf &b) {
-    if (b.n == 0.f) return;
-    const float n = a.n + b.n;
-    const float d = b.mean - a.mean;
-    const float f = b.n / n;
-    a.mean = fmaf(d, f, a.mean);
-    a.m2 = a.m2 + b.m2 + d * d * a.n * f;
-    a.n = n;
-}
-
-__global__ __launch_bounds__(256) void gn_partial_kernel(const TDesc in0, const TDesc in1, int groups,
-                                                         int slices, float *__restrict__ part) {
-    __shared__ float sn[256], smean[256], sm2[256];
+__global__ __launch_bounds__(256) void gn_partial_kernel(const TDesc in0, const TDesc in1, int slices,
+                                                         double *__restrict__ part) {
+    __shared__ double ssum[256][4], ssq[256][4];
     const int C0 = in0.C, C1 = in1.p ? in1.C : 0;
-    const int C = C0 + C1, Cg = C / groups;
+    const int C = C0 + C1, C4 = C >> 2;
     const int W = in0.W, HW = in0.H * in0.W;
     const int slice = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
     const int per = (HW + slices - 1) / slices;
     const int p0 = slice * per;
     const int p1 = min(HW, p0 + per);
-    const int CP = (C <= 256) ? C : (256 / Cg) * Cg;   // channels per pass (multiple of Cg)
-    for (int cbase = 0; cbase < C; cbase += CP) {
-        const int cw = min(CP, C - cbase);
-        const int plw = 256 / cw;
-        const int c = cbase + (t % cw);
-        const int pl = t / cw;
-        Wf s = {0.f, 0.f, 0.f};
+    // channel quads are processed in passes of QP quads; threads (pl, q) with q = t % QP
+    const int QP = min(C4, 256);
+    for (int qbase = 0; qbase < C4; qbase += QP) {
+        const int qw = min(QP, C4 - qbase);
+        const int plw = 256 / qw;
+        const int q = qbase + (t % qw);
+        const int pl = t / qw;
+        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
         if (pl < plw) {
+            const int c = q << 2;
             const TDesc &d = (c < C0) ? in0 : in1;
             const int cl = (c < C0) ? c : c - C0;
             const size_t cs = d.C;
@@ -66,31 +53,31 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const TDesc in0, const 
             const float *src = d.p + d.pix(n, 0, 0) * cs + cl;   // interior origin of image n
 #pragma unroll 4
             for (; pp < p1; pp += plw) {
-                wf_push(s, src[((size_t)y * Wp + x) * cs]);
+                const float4 v = *reinterpret_cast<const float4 *>(src + ((size_t)y * Wp + x) * cs);
+                s[0] += v.x; ss[0] = fma((double)v.x, (double)v.x, ss[0]);
+                s[1] += v.y; ss[1] = fma((double)v.y, (double)v.y, ss[1]);
+                s[2] += v.z; ss[2] = fma((double)v.z, (double)v.z, ss[2]);
+                s[3] += v.w; ss[3] = fma((double)v.w, (double)v.w, ss[3]);
                 x += plw;
                 while (x >= W) { x -= W; ++y; }
             }
         }
-        sn[t] = s.n; smean[t] = s.mean; sm2[t] = s.m2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[t][j] = s[j]; ssq[t][j] = ss[j]; }
         __syncthreads();
-        const int gp = cw / Cg;
-        if (t < gp) {
-            Wf a = {0.f, 0.f, 0.f};
-            for (int l = 0; l < plw; ++l)
-                for (int cc = 0; cc < Cg; ++cc) {
-                    const int i = l * cw + t * Cg + cc;
-                    Wf b = {sn[i], smean[i], sm2[i]};
-                    wf_merge(a, b);
-                }
-            const int g = cbase / Cg + t;
-            float *o = part + (((size_t)n * slices + slice) * groups + g) * 3;
-            o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
+        // thread (q', j) adds the pixel lanes of channel 4*(qbase+q') + j
+        for (int i = t; i < qw * 4; i += 256) {
+            const int qq = i >> 2, j = i & 3;
+            double a = 0, b = 0;
+            for (int l = 0; l < plw; ++l) { a += ssum[l * qw + qq][j]; b += ssq[l * qw + qq][j]; }
+            double *o = part + (((size_t)n * slices + slice) * C + ((qbase + qq) << 2) + j) * 2;
+            o[0] = a; o[1] = b;
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ part, int C,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part, int C, int HW,
                                                           int groups, int slices,
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
@@ -100,14 +87,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
     const int n = blockIdx.x, t = threadIdx.x;
     const int Cg = C / groups;
     for (int g = t; g < groups; g += blockDim.x) {
-        Wf a = {0.f, 0.f, 0.f};
+        double a = 0, b = 0;
         for (int s = 0; s < slices; ++s) {
-            const float *o = part + (((size_t)n * slices + s) * groups + g) * 3;
-            Wf b = {o[0], o[1], o[2]};
-            wf_merge(a, b);
+            const double *o = part + (((size_t)n * slices + s) * C + (size_t)g * Cg) * 2;
+            for (int cc = 0; cc < Cg; ++cc) { a += o[2 * cc]; b += o[2 * cc + 1]; }
         }
-        sm[g] = a.mean;
-        sm[groups + g] = 1.0f / sqrtf(a.m2 / a.n + eps);
+        const double cnt = (double)Cg * HW;
+        const double mean = a / cnt;
+        const double var = fmax(b / cnt - mean * mean, 0.0);
+        sm[g] = (float)mean;
+        sm[groups + g] = 1.0f / sqrtf((float)var + eps);
     }
     __syncthreads();
     for (int c = t; c < C; c += blockDim.x) {
@@ -121,7 +110,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 } // namespace
 
 static int gn_slices(int B, int HW) {
-    int s = 1024 / (B > 0 ? B : 1);
+    int s = 2048 / (B > 0 ? B : 1);
     if (s < 1) s = 1;
     int cap = HW / 64;
     if (cap < 1) cap = 1;
@@ -130,15 +119,18 @@ static int gn_slices(int B, int HW) {
     return s;
 }
 
-size_t gn_workspace_floats(int B, int groups) { return (size_t)B * GN_MAX_SLICES * groups * 3; }
+// workspace in floats: B * slices * C channels * 2 doubles
+size_t gn_workspace_floats(int B, int c_max) { return (size_t)B * GN_MAX_SLICES * c_max * 4; }
 
 void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int groups, const float *gamma,
                              const float *beta, float eps, float *part, float *scale, float *shift,
                              hipStream_t s) {
-    const int slices = gn_slices(B, in0.H * in0.W);
+    const int HW = in0.H * in0.W;
+    const int slices = gn_slices(B, HW);
     const int C = in0.C + (in1.p ? in1.C : 0);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, in1, groups, slices, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, part, C,
+    double *dpart = reinterpret_cast<double *>(part);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, in1, slices, dpart);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, dpart, C, HW,
                        groups, slices, gamma, beta, eps, scale, shift);
 }
 
@@ -158,43 +150,49 @@ template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, const TDesc out) {
-    // grid: x = chunks of (pixel-in-row, channel quad), y = n * H + row
-    const int C0 = in0.C, C = out.C, C4 = C >> 2;
+    // a thread owns 8 consecutive channels of one pixel (two 16-B loads, 16-B stores);
+    // grid: x = chunks of (pixel-in-row, channel octet), y = n * H + row
+    const int C0 = in0.C, C = out.C, C8 = C >> 3;
     const int n = blockIdx.y / out.H, y = blockIdx.y - n * out.H;
     const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= out.W * C4) return;
-    const int x = item / C4;
-    const int c = (item - x * C4) << 2;
-    const float4 *src = (c < C0)
-        ? reinterpret_cast<const float4 *>(in0.p + in0.pix(n, y, x) * C0 + c)
-        : reinterpret_cast<const float4 *>(in1.p + in1.pix(n, y, x) * in1.C + (c - C0));
-    float4 v = *src;
+    if (item >= out.W * C8) return;
+    const int x = item / C8;
+    const int c = (item - x * C8) << 3;
+    const float *src = (c < C0) ? in0.p + in0.pix(n, y, x) * C0 + c
+                                : in1.p + in1.pix(n, y, x) * in1.C + (c - C0);
+    const float4 v0 = *reinterpret_cast<const float4 *>(src);
+    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+    float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     if (MODE != 0) {
-        const float4 sc = *reinterpret_cast<const float4 *>(scale + (size_t)n * C + c);
-        const float4 sh = *reinterpret_cast<const float4 *>(shift + (size_t)n * C + c);
-        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        const float *scp = scale + (size_t)n * C + c, *shp = shift + (size_t)n * C + c;
+        const float4 s0 = *reinterpret_cast<const float4 *>(scp), s1 = *reinterpret_cast<const float4 *>(scp + 4);
+        const float4 h0 = *reinterpret_cast<const float4 *>(shp), h1 = *reinterpret_cast<const float4 *>(shp + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
     }
     if (MODE == 2) {
-        v.x = swish_fast(v.x); v.y = swish_fast(v.y); v.z = swish_fast(v.z); v.w = swish_fast(v.w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
     }
     float *dst = out.p + out.pix(n, y, x) * C;
     if (SPLIT) {
         // chunk of 32 channels = 128 B: halfs [0,32) hi, [32,64) lo; x = hi + lo to ~2^-22 |x|
         const float lim = 65504.0f;
-        float f[4] = {fminf(fmaxf(v.x, -lim), lim), fminf(fmaxf(v.y, -lim), lim),
-                      fminf(fmaxf(v.z, -lim), lim), fminf(fmaxf(v.w, -lim), lim)};
-        h16x4 hi, lo;
+        h16x8 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            hi[j] = (_Float16)f[j];
-            lo[j] = (_Float16)(f[j] - (float)hi[j]);
+        for (int j = 0; j < 8; ++j) {
+            const float g = fminf(fmaxf(f[j], -lim), lim);
+            hi[j] = (_Float16)g;
+            lo[j] = (_Float16)(g - (float)hi[j]);
         }
         _Float16 *hd = reinterpret_cast<_Float16 *>(dst + (c & ~31)) + (c & 31);
-        *reinterpret_cast<h16x4 *>(hd) = hi;
-        *reinterpret_cast<h16x4 *>(hd + 32) = lo;
+        *reinterpret_cast<h16x8 *>(hd) = hi;
+        *reinterpret_cast<h16x8 *>(hd + 32) = lo;
     } else {
-        *reinterpret_cast<float4 *>(dst + c) = v;
+        *reinterpret_cast<float4 *>(dst + c) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4 *>(dst + c + 4) = make_float4(f[4], f[5], f[6], f[7]);
     }
 }
 
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
 
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
                      int mode, int split, const TDesc &out, hipStream_t s) {
-    const int items = out.W * (out.C >> 2);
+    const int items = out.W * (out.C >> 3);
     const dim3 grid((items + 255) / 256, B * out.H);
 #define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out)
     if (split) {

@@ -417,7 +417,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t o_r = cv.take(max_rb);
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
-    const uint64_t o_gp = cv.take(gn_workspace_floats(B, g.norm_groups));
+    const uint64_t o_gp = cv.take(gn_workspace_floats(B, c->c_max));
     const uint64_t o_te = cv.take((uint64_t)B * g.inner_channel);
     const uint64_t o_cb = cv.take((uint64_t)B * c->nf_total);
     const uint64_t o_eps = cv.take((uint64_t)B * HW * g.out_channel);
@@ -997,7 +997,7 @@ int sr3_op_groupnorm_affine(sr3_ctx *c, const float *in0_dev, int C0, const floa
     float *dg = nullptr, *db = nullptr, *part = nullptr;
     HIP_OK(hipMalloc(&dg, (size_t)C * sizeof(float)));
     HIP_OK(hipMalloc(&db, (size_t)C * sizeof(float)));
-    HIP_OK(hipMalloc(&part, gn_workspace_floats(B, groups) * sizeof(float)));
+    HIP_OK(hipMalloc(&part, gn_workspace_floats(B, C) * sizeof(float)));
     HIP_OK(hipMemcpy(dg, gamma_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(db, beta_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice));
     launch_groupnorm_affine(unpadded(const_cast<float *>(in0_dev), C0, H, W),

@@ -52,7 +52,7 @@ float split_conv_weight(const float *packed, size_t rows, int CinPad, float *dst
 
 // ---- GroupNorm (kernels_misc.hip) -------------------------------------------------------------
 // statistics over the virtual concatenation in0 ‖ in1 -> folded affine scale/shift [B][C]
-size_t gn_workspace_floats(int B, int groups);
+size_t gn_workspace_floats(int B, int c_max);   // c_max = widest normalised tensor
 void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int groups, const float *gamma,
                              const float *beta, float eps, float *part, float *scale, float *shift,
                              hipStream_t s);
