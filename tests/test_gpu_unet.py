@@ -89,6 +89,7 @@ def test_torch_facade_state_dict_and_forward():
     with pytest.raises(pkg("_lib").Sr3Error, match="no CPU fallback"):
         netG.denoise_fn(torch.from_numpy(g["x"]), torch.from_numpy(g["noise_level"]))
     netG = netG.cuda()
+    assert netG.denoise_fn.precision == "f16x3"
     sd = {"denoise_fn." + k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, g["meta"]["seed"]).items()}
     res = netG.load_state_dict(sd, strict=False)
     assert not res.missing_keys and not res.unexpected_keys
@@ -100,3 +101,7 @@ def test_torch_facade_state_dict_and_forward():
         netG.denoise_fn.final_conv.block[3].bias.add_(1.0)
     eps2 = netG.denoise_fn(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["noise_level"]).cuda())
     np.testing.assert_allclose(eps2.cpu().numpy(), eps.cpu().numpy() + 1.0, atol=1e-5)
+    # switching the arithmetic at run time: exact-f32 and split-f16 agree to fp32 rounding level
+    netG.denoise_fn.precision = "f32"
+    eps3 = netG.denoise_fn(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["noise_level"]).cuda())
+    assert np.abs(eps3.cpu().numpy() - eps2.cpu().numpy()).max() < 1e-5
