@@ -369,6 +369,14 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0 || (H % div) || (W % div))
         return fail("unsupported shape B=%d H=%d W=%d: H and W must be multiples of %d", B, H, W, div);
     if ((uint64_t)B * (H + 2) * (W + 2) >= (1ull << 31)) return fail("B*H*W too large for 32-bit pixel indices");
+    {   // the conv's LDS-DMA addressing uses 32-bit byte offsets inside one tensor
+        uint64_t cmax = (uint64_t)c->in_pad;
+        for (auto &p : c->params)
+            if (p.kind == P_CONV) cmax = std::max<uint64_t>(cmax, (uint64_t)std::max(p.cin_pad, p.cout));
+        if ((uint64_t)B * (H + 2) * (W + 2) * cmax * sizeof(float) >= (1ull << 32))
+            return fail("batch %d at %dx%d makes an activation tensor >= 4 GiB; run at most %llu images per call",
+                        B, H, W, (unsigned long long)(((1ull << 32) - 1) / ((uint64_t)(H + 2) * (W + 2) * cmax * 4)));
+    }
     if (c->arena) {
         HIP_OK(hipStreamSynchronize(c->stream));
         HIP_OK(hipFree(c->arena));
