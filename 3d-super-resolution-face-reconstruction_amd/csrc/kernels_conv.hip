@@ -98,7 +98,8 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
     constexpr int TAPS = KS * KS;
-    const int nk = TAPS * (Cin / BK);
+    const int C2 = p.in2.p ? p.in2.C : 0;          // fused 1x1 term (res_conv)
+    const int nk = TAPS * (Cin / BK) + C2 / BK;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -149,11 +150,20 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
                 vA1[i] = pixbase * (unsigned)C1 * 4u + schunk16;
             }
         });
-        unsigned vB[BR];
+        unsigned vB[BR], vB2[BR], vA2[AR];
         static_for<BR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
             vB[i] = (unsigned)n * (unsigned)Cin * 4u + schunk16;
+            vB2[i] = (unsigned)n * (unsigned)C2 * 4u + schunk16;
+        });
+        static_for<AR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
+            const int n = m / HWo;
+            const int rem = m - n * HWo;
+            const int oy = rem / p.Wout;
+            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)C2 * 4u + schunk16 : 0u;
         });
         const size_t tapstride = (size_t)Cout * Cin;   // floats between taps of the packed weights
 
@@ -188,6 +198,23 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
                 __syncthreads();
                 ++k;
             });
+        }
+        // fused 1x1 term: K-steps over the channels of in2, read at the output pixel
+        for (int c0 = 0; c0 < C2; c0 += BK) {
+            float *Ad = smem + (k & 1) * STAGE + w * 256;
+            float *Bd = smem + (k & 1) * STAGE + BM * ROWF + w * 256;
+            const char *ab = reinterpret_cast<const char *>(p.in2.p + c0);
+            const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
+            static_for<AR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                dma16(reinterpret_cast<const float *>(ab + vA2[i]), Ad + i * 1024);
+            });
+            static_for<BR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
+            });
+            __syncthreads();
+            ++k;
         }
         __syncthreads();
         return;
@@ -404,16 +431,20 @@ void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, 
 // fp32 packed rows [rows][CinPad] -> per 32-channel chunk: 32 hi halfs | 32 lo halfs of w * 2^k,
 // k chosen so that max|w| * 2^k is in [1024, 2048): hi and lo are then normal fp16 numbers for all
 // but vanishing weights and w = (hi + lo) * 2^-k to ~2^-22 relative. Returns 2^-k.
-float split_conv_weight(const float *packed, size_t rows, int CinPad, float *dst) {
+int split_scale_exponent(const float *packed, size_t n) {
     float mx = 0.f;
-    const size_t n = rows * (size_t)CinPad;
     for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(packed[i]));
-    int k = 0;
-    if (mx > 0.f) {
-        int e;
-        frexpf(mx, &e);          // mx = f * 2^e, f in [0.5, 1)
-        k = 11 - e;              // mx * 2^k in [1024, 2048)
-    }
+    if (!(mx > 0.f)) return 0;
+    int e;
+    frexpf(mx, &e);              // mx = f * 2^e, f in [0.5, 1)
+    return 11 - e;               // mx * 2^k in [1024, 2048)
+}
+
+float split_conv_weight(const float *packed, size_t rows, int CinPad, float *dst) {
+    return split_conv_weight_k(packed, rows, CinPad, split_scale_exponent(packed, rows * (size_t)CinPad), dst);
+}
+
+float split_conv_weight_k(const float *packed, size_t rows, int CinPad, int k, float *dst) {
     const float sc = ldexpf(1.0f, k);
     _Float16 *d = reinterpret_cast<_Float16 *>(dst);
     for (size_t r = 0; r < rows; ++r)

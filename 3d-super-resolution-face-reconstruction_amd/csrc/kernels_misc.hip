@@ -146,37 +146,8 @@ __device__ __forceinline__ float swish_fast(float x) {
     return x * __frcp_rn(1.0f + __expf(-x));
 }
 
-template <int MODE, int SPLIT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
-                                                       const float *__restrict__ scale,
-                                                       const float *__restrict__ shift, const TDesc out) {
-    // a thread owns 8 consecutive channels of one pixel (two 16-B loads, 16-B stores);
-    // grid: x = chunks of (pixel-in-row, channel octet), y = n * H + row
-    const int C0 = in0.C, C = out.C, C8 = C >> 3;
-    const int n = blockIdx.y / out.H, y = blockIdx.y - n * out.H;
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= out.W * C8) return;
-    const int x = item / C8;
-    const int c = (item - x * C8) << 3;
-    const float *src = (c < C0) ? in0.p + in0.pix(n, y, x) * C0 + c
-                                : in1.p + in1.pix(n, y, x) * in1.C + (c - C0);
-    const float4 v0 = *reinterpret_cast<const float4 *>(src);
-    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
-    float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    if (MODE != 0) {
-        const float *scp = scale + (size_t)n * C + c, *shp = shift + (size_t)n * C + c;
-        const float4 s0 = *reinterpret_cast<const float4 *>(scp), s1 = *reinterpret_cast<const float4 *>(scp + 4);
-        const float4 h0 = *reinterpret_cast<const float4 *>(shp), h1 = *reinterpret_cast<const float4 *>(shp + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
-    }
-    if (MODE == 2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
-    }
-    float *dst = out.p + out.pix(n, y, x) * C;
+template <int SPLIT>
+__device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8]) {
     if (SPLIT) {
         // chunk of 32 channels = 128 B: halfs [0,32) hi, [32,64) lo; x = hi + lo to ~2^-22 |x|
         const float lim = 65504.0f;
@@ -196,13 +167,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
     }
 }
 
+template <int MODE, int SPLIT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, const TDesc out,
+                                                       const TDesc raw) {
+    // a thread owns 8 consecutive channels of one pixel (two 16-B loads, 16-B stores);
+    // grid: x = chunks of (pixel-in-row, channel octet), y = n * H + row
+    const int C0 = in0.C, C = out.C, C8 = C >> 3;
+    const int n = blockIdx.y / out.H, y = blockIdx.y - n * out.H;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= out.W * C8) return;
+    const int x = item / C8;
+    const int c = (item - x * C8) << 3;
+    const float *src = (c < C0) ? in0.p + in0.pix(n, y, x) * C0 + c
+                                : in1.p + in1.pix(n, y, x) * in1.C + (c - C0);
+    const float4 v0 = *reinterpret_cast<const float4 *>(src);
+    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
+    float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f);
+    if (MODE != 0) {
+        const float *scp = scale + (size_t)n * C + c, *shp = shift + (size_t)n * C + c;
+        const float4 s0 = *reinterpret_cast<const float4 *>(scp), s1 = *reinterpret_cast<const float4 *>(scp + 4);
+        const float4 h0 = *reinterpret_cast<const float4 *>(shp), h1 = *reinterpret_cast<const float4 *>(shp + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
+    }
+    store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f);
+}
+
 } // namespace
 
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, int split, const TDesc &out, hipStream_t s) {
+                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw) {
     const int items = out.W * (out.C >> 3);
     const dim3 grid((items + 255) / 256, B * out.H);
-#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out)
+#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw)
     if (split) {
         if (mode == 0) SR3_GA(0, 1); else if (mode == 1) SR3_GA(1, 1); else SR3_GA(2, 1);
     } else {

@@ -50,6 +50,8 @@ struct Param {
     float *dev = nullptr;                        // device storage (kernel layout)
     float *dev_split = nullptr;                  // P_CONV: split-f16 copy (prec 1), same size
     float w_unscale = 1.0f;
+    bool keep_host = false;                      // part of a fused (conv2 + res_conv) launch
+    std::vector<float> host;                     // packed fp32 weights / bias kept for re-scaling
     size_t dev_floats = 0;
     bool owns = true;                            // false: a view into a concatenated buffer
     bool loaded = false;
@@ -64,6 +66,7 @@ struct ResBlock {
     ConvRef c1, c2, res, qkv, aout;
     int nf_off = 0;  // offset into the concatenated FeatureWiseAffine output
     bool has_res = false, attn = false;
+    float *fused_bias = nullptr;   // has_res: conv2 bias + res_conv bias (the fused launch adds both)
 };
 
 enum ModKind { M_CONV_IN, M_RES, M_DOWN, M_UP };
@@ -75,7 +78,8 @@ struct Module {
     TDesc out;      // module output (zero-bordered)
     TDesc rb_out;   // ResBlock output before attention (== out if no attention)
     TDesc act1, act2, h1;   // activated conv inputs and the block1 output (per-shape buffers)
-    TDesc up_in;            // M_UP: split-f16 copy of the input (prec 1)
+    TDesc up_in;            // M_UP / M_DOWN: split-f16 copy of the raw input (prec 1)
+    TDesc raw1;             // has_res: un-normalised x ‖ skip in the conv input format (fused res_conv)
     int oc = 0, oh = 0, ow = 0;
 };
 
@@ -102,6 +106,7 @@ struct sr3_ctx {
     int c_max = 0;      // widest GroupNorm input
     uint64_t weight_bytes = 0;
     int prec = 0;       // 0 exact f32 MFMA, 1 split-f16 (f16x3) for the 3x3 / activated-input convs
+    bool fused_dirty = true;   // fused bias / common weight scales need (re)building
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -221,7 +226,10 @@ Module make_res(sr3_ctx *c, const std::string &prefix, int cin, int cout, bool a
     rb.gn2 = add_gn(c, rp + ".block2.block.0", cout);
     rb.c2 = add_conv(c, rp + ".block2.block.3", cout, cout, 3, true);
     rb.has_res = (cin != cout);
-    if (rb.has_res) rb.res = add_conv(c, rp + ".res_conv", cin, cout, 1, true);
+    if (rb.has_res) {
+        rb.res = add_conv(c, rp + ".res_conv", cin, cout, 1, true);
+        for (int idx : {rb.c2.w, rb.c2.b, rb.res.w, rb.res.b}) c->params[idx].keep_host = true;
+    }
     if (attn) {
         rb.agn = add_gn(c, prefix + ".attn.norm", cout);
         rb.qkv = add_conv(c, prefix + ".attn.qkv", cout, 3 * cout, 1, false);
@@ -369,14 +377,6 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0 || (H % div) || (W % div))
         return fail("unsupported shape B=%d H=%d W=%d: H and W must be multiples of %d", B, H, W, div);
     if ((uint64_t)B * (H + 2) * (W + 2) >= (1ull << 31)) return fail("B*H*W too large for 32-bit pixel indices");
-    {   // the conv's LDS-DMA addressing uses 32-bit byte offsets inside one tensor
-        uint64_t cmax = (uint64_t)c->in_pad;
-        for (auto &p : c->params)
-            if (p.kind == P_CONV) cmax = std::max<uint64_t>(cmax, (uint64_t)std::max(p.cin_pad, p.cout));
-        if ((uint64_t)B * (H + 2) * (W + 2) * cmax * sizeof(float) >= (1ull << 32))
-            return fail("batch %d at %dx%d makes an activation tensor >= 4 GiB; run at most %llu images per call",
-                        B, H, W, (unsigned long long)(((1ull << 32) - 1) / ((uint64_t)(H + 2) * (W + 2) * cmax * 4)));
-    }
     if (c->arena) {
         HIP_OK(hipStreamSynchronize(c->stream));
         HIP_OK(hipFree(c->arena));
@@ -384,9 +384,9 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     }
     // dry run over the graph for sizes
     Carver cv;
-    ShapePool acts, h1s;
+    ShapePool acts, h1s, raws;
     const size_t nm = c->mods.size();
-    std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm);
+    std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
     uint64_t max_rb = 0, max_qkv = 0, max_ao = 0;
     int h = H, w = W;
     int cur_c = c->in_pad;
@@ -395,13 +395,14 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         Module &m = c->mods[i];
         int oc;
         if (m.kind == M_CONV_IN) { oc = m.conv.cout; }
-        else if (m.kind == M_DOWN) { oc = m.conv.cout; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+        else if (m.kind == M_DOWN) { oc = m.conv.cout; a1_off[i] = acts.get(cv, B, m.conv.cin, h, w); a2_off[i] = h * 65536 + w; h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
         else if (m.kind == M_UP) { oc = m.conv.cout; a1_off[i] = acts.get(cv, B, m.conv.cin, h, w); a2_off[i] = h * 65536 + w; h *= 2; w *= 2; }
         else {
             oc = m.rb.cout;
             a1_off[i] = acts.get(cv, B, m.rb.cin, h, w);
             a2_off[i] = acts.get(cv, B, oc, h, w);
             h1_off[i] = h1s.get(cv, B, oc, h, w);
+            if (m.rb.has_res) raw_off[i] = raws.get(cv, B, m.rb.cin, h, w);
             const uint64_t n = (uint64_t)B * (h + 2) * (w + 2) * oc;
             if (n > max_rb) max_rb = n;
             if (m.rb.attn) {
@@ -419,6 +420,23 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     }
     (void)cur_c;
     if (h != H || w != W) return fail("internal: UNet does not return to the input resolution");
+    {   // the conv's LDS-DMA addressing uses 32-bit byte offsets inside one tensor
+        uint64_t mx = (uint64_t)B * (H + 2) * (W + 2) * c->in_pad;
+        int hh = H, ww = W;
+        for (size_t i = 0; i < nm; ++i) {
+            const Module &m = c->mods[i];
+            uint64_t ch = m.oc;
+            if (m.kind == M_RES) ch = std::max<uint64_t>(ch, m.rb.attn ? 3ull * m.rb.cout : (uint64_t)m.rb.cin);
+            if (m.kind == M_RES) ch = std::max<uint64_t>(ch, (uint64_t)m.rb.cin);
+            mx = std::max(mx, (uint64_t)B * (m.oh + 2) * (m.ow + 2) * ch);
+            hh = m.oh; ww = m.ow;
+        }
+        (void)hh; (void)ww;
+        if (mx * sizeof(float) >= (1ull << 32))
+            return fail("batch %d at %dx%d makes an activation tensor of %.1f GiB (limit 4 GiB: 32-bit DMA offsets); "
+                        "run at most %llu images per call", B, H, W, mx * 4.0 / (1ull << 30),
+                        (unsigned long long)((uint64_t)B * ((1ull << 32) - 1) / (mx * 4)));
+    }
     const uint64_t o_fa = acts.get(cv, B, c->final_gn.C, H, W);
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t o_x0 = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
@@ -442,11 +460,12 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         Module &m = c->mods[i];
         m.out = desc(out_off[i], m.oc, m.oh, m.ow, 1);
         m.rb_out = desc(rb_off[i], m.oc, m.oh, m.ow, 1);
-        if (m.kind == M_UP) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);
+        if (m.kind == M_UP || m.kind == M_DOWN) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);
         if (m.kind == M_RES) {
             m.act1 = desc(a1_off[i], m.rb.cin, m.oh, m.ow, 1);
             m.act2 = desc(a2_off[i], m.oc, m.oh, m.ow, 1);
             m.h1 = desc(h1_off[i], m.oc, m.oh, m.ow, 1);
+            if (m.rb.has_res) m.raw1 = desc(raw_off[i], m.rb.cin, m.oh, m.ow, 1);
         }
     }
     c->x0 = desc(o_x0, c->in_pad, H, W, 1);
@@ -465,33 +484,39 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
 const TDesc kNone{};
 
 // GroupNorm statistics + apply (+Swish) (+concat) -> activated, zero-bordered conv input
-void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act) {
+void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act,
+                const TDesc &raw = TDesc()) {
     c->pbegin(F_GN);
     launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
                             c->gpart, c->gscale, c->gshift, c->stream);
-    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream);
+    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw);
     c->pend();
 }
 
 // `activated`: the input was written by launch_gn_apply and is in the context's precision format
 void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int B, int stride, int up2,
-              const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false) {
+              const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false,
+              const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
     p.prec = activated ? c->prec : 0;
     p.w = p.prec ? c->params[cv.w].dev_split : c->params[cv.w].dev;
     p.w_unscale = c->params[cv.w].w_unscale;
-    p.bias = cv.b >= 0 ? c->params[cv.b].dev : nullptr;
+    p.bias = bias_override ? bias_override : (cv.b >= 0 ? c->params[cv.b].dev : nullptr);
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
     p.resid = resid; p.out = out;
+    if (cv2) {
+        p.in2 = in2;
+        p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;
+    }
     c->pbegin(F_CONV);
     launch_conv(p, c->stream);
     if (c->prof) {
         char tag[160];
-        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d prec%d", cv.ks, stride, up2, out.H,
-                 out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, p.prec);
-        c->pend(2.0 * (double)B * out.H * out.W * cv.cout * (double)(cv.ks * cv.ks) * cv.cin, tag);
+        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d fused1x1:%d prec%d", cv.ks, stride,
+                 up2, out.H, out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, cv2 ? cv2->cin : 0, p.prec);
+        c->pend(2.0 * (double)B * out.H * out.W * cv.cout * ((double)(cv.ks * cv.ks) * cv.cin + (cv2 ? cv2->cin : 0)), tag);
     }
 }
 
@@ -503,16 +528,17 @@ TDesc unpadded(float *p, int C, int H, int W) {
 void run_res(sr3_ctx *c, Module &m, const TDesc &x, const TDesc &skip, int B) {
     const ResBlock &rb = m.rb;
     const int h = m.oh, w = m.ow;
-    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1);
+    // block1: GN+Swish(x ‖ skip) -> conv3x3 + bias + FeatureWiseAffine bias; the same pass stores
+    // the raw concatenation for the fused res_conv
+    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1, rb.has_res ? m.raw1 : kNone);
     run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true);
-    TDesc resid = x;
-    if (rb.has_res) {
-        TDesc r = m.rb_out; r.p = c->rbuf;          // same geometry as the block output
-        run_conv(c, x, skip, rb.res, B, 1, 0, nullptr, kNone, r);
-        resid = r;
-    }
     run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2);
-    run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, resid, m.rb_out, true);
+    // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
+    // K-steps | + x as residual when the block keeps its width]
+    if (rb.has_res)
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, m.raw1, &rb.res, rb.fused_bias);
+    else
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x, m.rb_out, true);
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2);
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
@@ -537,7 +563,14 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
             run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out);
             break;
         case M_DOWN:
-            run_conv(c, cur, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out);
+            if (c->prec) {
+                c->pbegin(F_GN);
+                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
+                c->pend();
+                run_conv(c, m.up_in, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out, true);
+            } else {
+                run_conv(c, cur, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out);
+            }
             break;
         case M_UP:
             if (c->prec) {   // the raw module output is re-stored in split-f16 form for the fast conv
@@ -579,12 +612,38 @@ void run_embed(sr3_ctx *c, const float *nl, int stride, int B) {
     c->pend();
 }
 
+// ResnetBlocks with a res_conv run conv2 and the 1x1 res_conv as ONE launch (extra K-steps): the
+// two biases are pre-added and, for the split-f16 weights, both tensors get the same 2^k scale.
+int prepare_fused(sr3_ctx *c) {
+    if (!c->fused_dirty) return 0;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    for (auto &m : c->mods) {
+        if (m.kind != M_RES || !m.rb.has_res) continue;
+        ResBlock &rb = m.rb;
+        Param &w2 = c->params[rb.c2.w], &wr = c->params[rb.res.w];
+        const Param &b2 = c->params[rb.c2.b], &br = c->params[rb.res.b];
+        std::vector<float> bsum(rb.cout);
+        for (int i = 0; i < rb.cout; ++i) bsum[i] = b2.host[i] + br.host[i];
+        if (!rb.fused_bias) HIP_OK(hipMalloc(&rb.fused_bias, (size_t)rb.cout * sizeof(float)));
+        HIP_OK(hipMemcpy(rb.fused_bias, bsum.data(), bsum.size() * sizeof(float), hipMemcpyHostToDevice));
+        const int k = std::min(split_scale_exponent(w2.host.data(), w2.host.size()),
+                               split_scale_exponent(wr.host.data(), wr.host.size()));
+        std::vector<float> sp(std::max(w2.host.size(), wr.host.size()));
+        w2.w_unscale = split_conv_weight_k(w2.host.data(), (size_t)9 * w2.cout, w2.cin_pad, k, sp.data());
+        HIP_OK(hipMemcpy(w2.dev_split, sp.data(), w2.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+        wr.w_unscale = split_conv_weight_k(wr.host.data(), (size_t)wr.cout, wr.cin_pad, k, sp.data());
+        HIP_OK(hipMemcpy(wr.dev_split, sp.data(), wr.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->fused_dirty = false;
+    return 0;
+}
+
 int check_ready(sr3_ctx *c) {
     if (!c) return fail("null context");
     HIP_OK(hipSetDevice(c->device));
     for (auto &p : c->params)
         if (!p.loaded) return fail("weight '%s' was never loaded (sr3_load_weight)", p.name.c_str());
-    return 0;
+    return prepare_fused(c);
 }
 
 int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
@@ -650,6 +709,8 @@ void sr3_destroy(sr3_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    for (auto &m : c->mods)
+        if (m.rb.fused_bias) (void)hipFree(m.rb.fused_bias);
     for (auto &p : c->params) {
         if (p.owns && p.dev) (void)hipFree(p.dev);
         if (p.dev_split) (void)hipFree(p.dev_split);
@@ -715,13 +776,16 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
             std::vector<float> packed(p.dev_floats);
             pack_conv_weight(host, p.cout, p.cin, p.ks, p.cin_pad, packed.data());
             HIP_OK(hipMemcpy(p.dev, packed.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+            if (p.keep_host) p.host = packed;
             std::vector<float> sp(p.dev_floats);
             p.w_unscale = split_conv_weight(packed.data(), (size_t)p.ks * p.ks * p.cout, p.cin_pad, sp.data());
             HIP_OK(hipMemcpy(p.dev_split, sp.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
         } else {
             HIP_OK(hipMemcpy(p.dev, host, p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+            if (p.keep_host) p.host.assign(host, host + p.dev_floats);
         }
         p.loaded = true;
+        c->fused_dirty = true;
         return 0;
     }
     return fail("unknown parameter '%s'", name);

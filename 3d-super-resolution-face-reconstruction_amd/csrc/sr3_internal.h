@@ -30,6 +30,10 @@ struct ConvParams {
     int Hout = 0, Wout = 0;
     int ks = 3, stride = 1, up2 = 0;
     const float *w = nullptr;          // packed [ks*ks][Cout][Cin]
+    // optional fused 1x1 term (ResnetBlock.res_conv, unet.py:102-103,110): out += in2 (*) w2, read at
+    // the output pixel; same precision format and (for prec 1) the same weight scale as w
+    TDesc in2;                         // p == nullptr if none; same H, W as the output
+    const float *w2 = nullptr;         // packed [Cout][in2.C]
     const float *bias = nullptr;       // [Cout] or null
     const float *chan_bias = nullptr;  // [B][chan_bias_stride] (+ offset applied by caller) or null
     int chan_bias_stride = 0;
@@ -59,8 +63,13 @@ void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int grou
 // out[n,y,x,:] = act(concat(in0,in1)[n,y,x,:] * scale[n,:] + shift[n,:]); mode 0 copy, 1 affine,
 // 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only. split != 0 stores every
 // 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format).
+// raw (optional, p != nullptr): additionally stores the un-normalised concatenation in the same
+// format (the input of a fused res_conv).
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, int split, const TDesc &out, hipStream_t s);
+                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw = TDesc());
+// common power-of-two scale for several weight tensors: returns k with max|w| * 2^k in [1024, 2048)
+int split_scale_exponent(const float *packed, size_t n);
+float split_conv_weight_k(const float *packed, size_t rows, int CinPad, int k, float *dst);
 
 // ---- attention core ----------------------------------------------------------------------------
 double launch_attention(const float *qkv, int B, int N, int C, float *out, hipStream_t s);
