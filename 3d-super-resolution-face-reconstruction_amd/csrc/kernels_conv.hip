@@ -217,6 +217,22 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
             ++k;
         }
         __syncthreads();
+        if (p.stats == nullptr) return;
+        // fused GroupNorm statistics: the consumers leave per-(wave row, lane half, column) sums in
+        // LDS; the producer threads add them and write this tile's per-channel partials
+        __syncthreads();
+        {
+            const double2 *red = reinterpret_cast<const double2 *>(smem);
+            const int col = threadIdx.x - 256;
+            if (col < BN && n0 + col < Cout) {
+                double a = 0, b = 0;
+#pragma unroll
+                for (int j = 0; j < WGM * 2; ++j) { const double2 v = red[j * BN + col]; a += v.x; b += v.y; }
+                const int n = m0 / HWo, slice = (m0 - n * HWo) / BM;
+                double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0 + col) * 2;
+                o[0] = a; o[1] = b;
+            }
+        }
         return;
     }
 
@@ -335,6 +351,7 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
         const int n = n0 + wn * WN + ni * 32 + li;
         const int nc = min(n, Cout - 1);
         const float bs = p.bias ? p.bias[nc] : 0.f;
+        double st1 = 0.0, st2 = 0.0;       // fused GroupNorm statistics of this lane's column
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -359,11 +376,16 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = m0 + rbase + j;
-                    if (m < M && n < Cout) p.out.p[o[j]] = acc[mi][ni][4 * rq + j] + add[j];
+                    const float v = acc[mi][ni][4 * rq + j] + add[j];
+                    if (m < M && n < Cout) p.out.p[o[j]] = v;
+                    if (p.stats != nullptr) { st1 += (double)v; st2 = fma((double)v, (double)v, st2); }
                 }
             }
         }
+        if (p.stats != nullptr)
+            reinterpret_cast<double2 *>(smem)[(wm * 2 + lh) * BN + wn * WN + ni * 32 + li] = make_double2(st1, st2);
     }
+    if (p.stats != nullptr) __syncthreads();
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
@@ -399,22 +421,27 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
 // Preconditions (checked by the callers in sr3_api.hip): channels multiples of 32, 3x3 inputs
 // zero-bordered (pad 1), up2 only with ks 3 / stride 1 / single input, every tensor < 4 GiB
 // (32-bit byte offsets in the DMA addressing).
+// tile choice: 0 = 128x32, 1 = 128x64, 2 = 64x64, 3 = 128x128
+static int conv_tile_choice(long M, int Cout) {
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+    const long want = 512;  // 256 CUs x 2 resident blocks
+    if (Cout <= 32) return 0;
+    if (Cout <= 64 || (Cout % 128) != 0) return blocks(128, 64) >= want ? 1 : 2;
+    if (blocks(128, 128) >= want) return 3;
+    return blocks(128, 64) >= want ? 1 : 2;
+}
+
+int conv_tile_m(long M, int Cout) { return conv_tile_choice(M, Cout) == 2 ? 64 : 128; }
+
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     ConvParams p = p_in;
     if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
     const long M = (long)p.B * p.Hout * p.Wout;
-    const int Cout = p.out.C;
-    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-    const long want = 512;  // 256 CUs x 2 resident blocks
-    if (Cout <= 32) {
-        launch_cfg<128, 32, 4, 1>(p, s);
-    } else if (Cout <= 64 || (Cout % 128) != 0) {
-        if (blocks(128, 64) >= want) launch_cfg<128, 64, 2, 2>(p, s);
-        else launch_cfg<64, 64, 2, 2>(p, s);
-    } else {
-        if (blocks(128, 128) >= want) launch_cfg<128, 128, 2, 2>(p, s);
-        else if (blocks(128, 64) >= want) launch_cfg<128, 64, 2, 2>(p, s);
-        else launch_cfg<64, 64, 2, 2>(p, s);
+    switch (conv_tile_choice(M, p.out.C)) {
+    case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
+    case 1: launch_cfg<128, 64, 2, 2>(p, s); break;
+    case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
+    default: launch_cfg<128, 128, 2, 2>(p, s); break;
     }
 }
 

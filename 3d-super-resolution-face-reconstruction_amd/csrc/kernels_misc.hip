@@ -77,26 +77,46 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const TDesc in0, const 
     }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part, int C, int HW,
-                                                          int groups, int slices,
-                                                          const float *__restrict__ gamma,
+// two partial sources (the halves of a concatenation may come from convs with different tilings)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part0, int C0, int slices0,
+                                                          const double *__restrict__ part1, int C1, int slices1,
+                                                          int HW, int groups, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
-                                                          float *__restrict__ scale,
-                                                          float *__restrict__ shift) {
+                                                          float *__restrict__ scale, float *__restrict__ shift) {
     extern __shared__ float sm[];  // mean[groups], rstd[groups]
+    __shared__ double ra[256], rb[256];
     const int n = blockIdx.x, t = threadIdx.x;
-    const int Cg = C / groups;
-    for (int g = t; g < groups; g += blockDim.x) {
+    const int C = C0 + C1, Cg = C / groups;
+    // (group, slice lane): 256 / gpp slice lanes per group, gpp groups per pass
+    const int gpp = min(groups, 256);
+    const int lanes = 256 / gpp;
+    for (int gbase = 0; gbase < groups; gbase += gpp) {
+        const int g = gbase + (t % gpp), sl0 = t / gpp;
         double a = 0, b = 0;
-        for (int s = 0; s < slices; ++s) {
-            const double *o = part + (((size_t)n * slices + s) * C + (size_t)g * Cg) * 2;
-            for (int cc = 0; cc < Cg; ++cc) { a += o[2 * cc]; b += o[2 * cc + 1]; }
+        if (g < groups && sl0 < lanes) {
+            for (int cc = 0; cc < Cg; ++cc) {
+                const int c = g * Cg + cc;
+                const bool first = c < C0;
+                const double *pp = first ? part0 : part1;
+                const int Cs = first ? C0 : C1, cl = first ? c : c - C0, sl = first ? slices0 : slices1;
+                for (int s = sl0; s < sl; s += lanes) {
+                    const double *o = pp + (((size_t)n * sl + s) * Cs + cl) * 2;
+                    a += o[0]; b += o[1];
+                }
+            }
         }
-        const double cnt = (double)Cg * HW;
-        const double mean = a / cnt;
-        const double var = fmax(b / cnt - mean * mean, 0.0);
-        sm[g] = (float)mean;
-        sm[groups + g] = 1.0f / sqrtf((float)var + eps);
+        ra[t] = a; rb[t] = b;
+        __syncthreads();
+        if (t < gpp && gbase + t < groups) {
+            double sa = 0, sb = 0;
+            for (int l = 0; l < lanes; ++l) { sa += ra[l * gpp + t]; sb += rb[l * gpp + t]; }
+            const double cnt = (double)Cg * HW;
+            const double mean = sa / cnt;
+            const double var = fmax(sb / cnt - mean * mean, 0.0);
+            sm[gbase + t] = (float)mean;
+            sm[groups + gbase + t] = 1.0f / sqrtf((float)var + eps);
+        }
+        __syncthreads();
     }
     __syncthreads();
     for (int c = t; c < C; c += blockDim.x) {
@@ -130,8 +150,15 @@ void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int grou
     const int C = in0.C + (in1.p ? in1.C : 0);
     double *dpart = reinterpret_cast<double *>(part);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, in1, slices, dpart);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, dpart, C, HW,
-                       groups, slices, gamma, beta, eps, scale, shift);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, dpart, C, slices,
+                       (const double *)nullptr, 0, 0, HW, groups, gamma, beta, eps, scale, shift);
+}
+
+void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, int C1, int B, int HW, int groups,
+                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, s0.p, C0, s0.slices,
+                       s1.p, C1, s1.slices, HW, groups, gamma, beta, eps, scale, shift);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -80,6 +80,9 @@ struct Module {
     TDesc act1, act2, h1;   // activated conv inputs and the block1 output (per-shape buffers)
     TDesc up_in;            // M_UP / M_DOWN: split-f16 copy of the raw input (prec 1)
     TDesc raw1;             // has_res: un-normalised x ‖ skip in the conv input format (fused res_conv)
+    // fused GroupNorm statistics written by the conv that produces out / rb_out / h1 (p == null:
+    // the tile does not divide the image, fall back to the statistics kernel)
+    StatsRef st_out, st_rb, st_h1;
     int oc = 0, oh = 0, ow = 0;
 };
 
@@ -107,6 +110,7 @@ struct sr3_ctx {
     uint64_t weight_bytes = 0;
     int prec = 0;       // 0 exact f32 MFMA, 1 split-f16 (f16x3) for the 3x3 / activated-input convs
     bool fused_dirty = true;   // fused bias / common weight scales need (re)building
+    bool no_fused_stats = false;   // SR3_NO_FUSED_STATS=1: always run the statistics kernel (A/B testing)
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -387,6 +391,8 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     ShapePool acts, h1s, raws;
     const size_t nm = c->mods.size();
     std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
+    std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm);
+    std::vector<int> s_slices(nm, 0);
     uint64_t max_rb = 0, max_qkv = 0, max_ao = 0;
     int h = H, w = W;
     int cur_c = c->in_pad;
@@ -413,6 +419,16 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             }
         }
         m.oc = oc; m.oh = h; m.ow = w;
+        {   // fused statistics: every conv writing an [oc, h, w] tensor uses the same tile height
+            const int bm = conv_tile_m((long)B * h * w, oc);
+            if ((h * w) % bm == 0) {
+                s_slices[i] = (h * w) / bm;
+                const uint64_t sf = (uint64_t)B * s_slices[i] * oc * 4;   // 2 doubles per channel
+                so_off[i] = cv.take(sf);
+                sr_off[i] = cv.take(sf);
+                sh_off[i] = cv.take(sf);
+            }
+        }
         const uint64_t n = (uint64_t)B * (h + 2) * (w + 2) * oc;
         out_off[i] = cv.take(n);
         rb_off[i] = (m.kind == M_RES && m.rb.attn) ? cv.take(n) : out_off[i];
@@ -460,6 +476,14 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         Module &m = c->mods[i];
         m.out = desc(out_off[i], m.oc, m.oh, m.ow, 1);
         m.rb_out = desc(rb_off[i], m.oc, m.oh, m.ow, 1);
+        m.st_out = m.st_rb = m.st_h1 = StatsRef();
+        if (s_slices[i]) {
+            m.st_out.p = reinterpret_cast<double *>(c->arena + so_off[i]);
+            m.st_rb.p = reinterpret_cast<double *>(c->arena + sr_off[i]);
+            m.st_h1.p = reinterpret_cast<double *>(c->arena + sh_off[i]);
+            m.st_out.slices = m.st_rb.slices = m.st_h1.slices = s_slices[i];
+            if (!(m.kind == M_RES && m.rb.attn)) m.st_rb = m.st_out;   // rb_out aliases out
+        }
         if (m.kind == M_UP || m.kind == M_DOWN) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);
         if (m.kind == M_RES) {
             m.act1 = desc(a1_off[i], m.rb.cin, m.oh, m.ow, 1);
@@ -485,10 +509,14 @@ const TDesc kNone{};
 
 // GroupNorm statistics + apply (+Swish) (+concat) -> activated, zero-bordered conv input
 void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act,
-                const TDesc &raw = TDesc()) {
+                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc()) {
     c->pbegin(F_GN);
-    launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
-                            c->gpart, c->gscale, c->gshift, c->stream);
+    if (sa.p && (!b.p || sb.p) && !c->no_fused_stats)
+        launch_groupnorm_finalize(sa, a.C, sb, b.p ? b.C : 0, B, a.H * a.W, c->cfg.norm_groups,
+                                  c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f, c->gscale, c->gshift, c->stream);
+    else
+        launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
+                                c->gpart, c->gscale, c->gshift, c->stream);
     launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw);
     c->pend();
 }
@@ -496,7 +524,8 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
 // `activated`: the input was written by launch_gn_apply and is in the context's precision format
 void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int B, int stride, int up2,
               const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false,
-              const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr) {
+              const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
+              const StatsRef &stats = StatsRef()) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
@@ -506,6 +535,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.bias = bias_override ? bias_override : (cv.b >= 0 ? c->params[cv.b].dev : nullptr);
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
     p.resid = resid; p.out = out;
+    if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
     if (cv2) {
         p.in2 = in2;
         p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;
@@ -525,28 +555,30 @@ TDesc unpadded(float *p, int C, int H, int W) {
 }
 
 // ResnetBlock.forward (unet.py:105-110) + SelfAttention.forward (unet.py:123-142)
-void run_res(sr3_ctx *c, Module &m, const TDesc &x, const TDesc &skip, int B) {
+// sx / ss: fused statistics of x / skip (written by the convs that produced them)
+void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TDesc &skip, const StatsRef &ss, int B) {
     const ResBlock &rb = m.rb;
     const int h = m.oh, w = m.ow;
     // block1: GN+Swish(x ‖ skip) -> conv3x3 + bias + FeatureWiseAffine bias; the same pass stores
     // the raw concatenation for the fused res_conv
-    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1, rb.has_res ? m.raw1 : kNone);
-    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true);
-    run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2);
+    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1, sx, ss, rb.has_res ? m.raw1 : kNone);
+    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1);
+    run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef());
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
     // K-steps | + x as residual when the block keeps its width]
     if (rb.has_res)
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, m.raw1, &rb.res, rb.fused_bias);
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, m.raw1, &rb.res, rb.fused_bias, m.st_rb);
     else
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x, m.rb_out, true);
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb);
     if (rb.attn) {
-        run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2);
+        run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
         run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv, true);
         c->pbegin(F_ATTN);
         const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
         c->pend(fl);
-        run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out);
+        run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out, false, kNone,
+                 nullptr, nullptr, m.st_out);
     }
 }
 
@@ -554,48 +586,43 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const TDesc &skip, int B) {
 void run_unet_body(sr3_ctx *c, int B, int H, int W) {
     std::vector<int> feats;
     TDesc cur = c->x0;
+    StatsRef scur;
     const int n_pre = c->n_downs + c->n_mid;
     for (int i = 0; i < (int)c->mods.size(); ++i) {
         Module &m = c->mods[i];
         const bool is_up_path = i >= n_pre;
         switch (m.kind) {
         case M_CONV_IN:
-            run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out);
+            run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out);
             break;
         case M_DOWN:
-            if (c->prec) {
-                c->pbegin(F_GN);
-                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
-                c->pend();
-                run_conv(c, m.up_in, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out, true);
-            } else {
-                run_conv(c, cur, kNone, m.conv, B, 2, 0, nullptr, kNone, m.out);
-            }
-            break;
-        case M_UP:
+        case M_UP: {
+            const int stride = m.kind == M_DOWN ? 2 : 1, up2 = m.kind == M_UP ? 1 : 0;
             if (c->prec) {   // the raw module output is re-stored in split-f16 form for the fast conv
                 c->pbegin(F_GN);
                 launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
                 c->pend();
-                run_conv(c, m.up_in, kNone, m.conv, B, 1, 1, nullptr, kNone, m.out, true);
+                run_conv(c, m.up_in, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out);
             } else {
-                run_conv(c, cur, kNone, m.conv, B, 1, 1, nullptr, kNone, m.out);
+                run_conv(c, cur, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out);
             }
             break;
+        }
         case M_RES:
             if (is_up_path) {
                 Module &sk = c->mods[feats.back()];
                 feats.pop_back();
-                run_res(c, m, cur, sk.out, B);
+                run_res(c, m, cur, scur, sk.out, sk.st_out, B);
             } else {
-                run_res(c, m, cur, kNone, B);
+                run_res(c, m, cur, scur, kNone, StatsRef(), B);
             }
             break;
         }
         cur = m.out;
+        scur = m.st_out;
         if (i < c->n_downs) feats.push_back(i);
     }
-    run_gn_act(c, cur, kNone, c->final_gn, B, 2, c->final_act);
+    run_gn_act(c, cur, kNone, c->final_gn, B, 2, c->final_act, scur, StatsRef());
     run_conv(c, c->final_act, kNone, c->final_conv, B, 1, 0, nullptr, kNone, c->eps, true);
     (void)H; (void)W;
 }
@@ -697,6 +724,7 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
     sr3_ctx *c = new sr3_ctx();
     c->cfg = *cfg;
     c->device = device;
+    if (const char *e = getenv("SR3_NO_FUSED_STATS")) c->no_fused_stats = atoi(e) != 0;
     if (build_graph(c)) { delete c; return -1; }
     if (alloc_weights(c)) { sr3_destroy(c); return -1; }
     if (hipStreamCreate(&c->own_stream) != hipSuccess) { sr3_destroy(c); return fail("hipStreamCreate failed"); }

@@ -37,6 +37,11 @@ struct ConvParams {
     const float *bias = nullptr;       // [Cout] or null
     const float *chan_bias = nullptr;  // [B][chan_bias_stride] (+ offset applied by caller) or null
     int chan_bias_stride = 0;
+    // optional fused GroupNorm statistics of the OUTPUT: per (image, M-tile-in-image, channel)
+    // {sum, sum of squares} in fp64 at stats[((n * stats_slices + slice) * Cout + c) * 2]; requires
+    // Hout*Wout % BM == 0 for the tile the launcher picks (launch_conv_tile_m tells)
+    double *stats = nullptr;
+    int stats_slices = 0;
     TDesc resid;            // p == nullptr if none; same geometry as out
     TDesc out;              // C = Cout
     // prec 0: exact f32 MFMA; inputs / weights are fp32.
@@ -49,6 +54,8 @@ struct ConvParams {
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
 void launch_conv(const ConvParams &p, hipStream_t s);
+// BM of the tile launch_conv will use for this problem (so callers can size / enable fused stats)
+int conv_tile_m(long M, int Cout);
 // host helper: OIHW -> [tap][Cout][CinPad] (zero pad input channels up to CinPad)
 void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, float *dst);
 // host helper: fp32 packed weights -> split-f16 layout (same byte size), returns the unscale factor
@@ -60,6 +67,11 @@ size_t gn_workspace_floats(int B, int c_max);   // c_max = widest normalised ten
 void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int groups, const float *gamma,
                              const float *beta, float eps, float *part, float *scale, float *shift,
                              hipStream_t s);
+// statistics already accumulated by the producing convs (ConvParams::stats): only the reduce
+struct StatsRef { const double *p = nullptr; int slices = 0; };
+void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, int C1, int B, int HW, int groups,
+                               const float *gamma, const float *beta, float eps, float *scale, float *shift,
+                               hipStream_t s);
 // out[n,y,x,:] = act(concat(in0,in1)[n,y,x,:] * scale[n,:] + shift[n,:]); mode 0 copy, 1 affine,
 // 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only. split != 0 stores every
 // 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format).
