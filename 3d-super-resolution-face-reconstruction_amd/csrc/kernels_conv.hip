@@ -66,8 +66,9 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 
 // KS: 1 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into the gather
 // PREC 0: exact f32 (v_mfma_f32_32x32x2_f32); PREC 1: split-f16, 3 x v_mfma_f32_32x32x16_f16
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
-__global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4) void conv_igemm_dma_f32(const ConvParams p) {
+// KPB: K-tiles per barrier interval (a pipeline stage holds KPB tiles); KPB 2 = one block per CU
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int KPB>
+__global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [2 stages][A: BM rows | B: BN rows][32 floats], then per-row tables for the epilogue
-    int *rowpix = reinterpret_cast<int *>(smem + 2 * STAGE);   // [BM] padded output pixel index
+    int *rowpix = reinterpret_cast<int *>(smem + 2 * KPB * STAGE);   // [BM] padded output pixel index
     int *rowimg = rowpix + BM;                                  // [BM] image index
 
     const int C0 = p.in0.C, C1 = p.in1.p ? p.in1.C : 0;
@@ -179,8 +180,8 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
             static_for<TAPS>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int dy = tap / KS, dx = tap % KS;
-                float *Ad = smem + (k & 1) * STAGE + w * 256;
-                float *Bd = smem + (k & 1) * STAGE + BM * ROWF + w * 256;
+                float *Ad = smem + (((k / KPB) & 1) * KPB + (k % KPB)) * STAGE + w * 256;
+                float *Bd = Ad + BM * ROWF;
                 if (!(p.dbg & 1) || k == 0) {
                     const char *ab = UP2 ? abase : abase + (size_t)(dy * Wp + dx) * Cs * 4;
                     if (p.dbg & 2) ab = reinterpret_cast<const char *>(p.in0.p);   // experiment: cache-hot source
@@ -195,14 +196,14 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
                         dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
                     });
                 }
-                __syncthreads();
+                if (KPB == 1 || (k % KPB) == KPB - 1 || k == nk - 1) __syncthreads();
                 ++k;
             });
         }
         // fused 1x1 term: K-steps over the channels of in2, read at the output pixel
         for (int c0 = 0; c0 < C2; c0 += BK) {
-            float *Ad = smem + (k & 1) * STAGE + w * 256;
-            float *Bd = smem + (k & 1) * STAGE + BM * ROWF + w * 256;
+            float *Ad = smem + (((k / KPB) & 1) * KPB + (k % KPB)) * STAGE + w * 256;
+            float *Bd = Ad + BM * ROWF;
             const char *ab = reinterpret_cast<const char *>(p.in2.p + c0);
             const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
             static_for<AR>([&](auto ic) {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
                 constexpr int i = decltype(ic)::value;
                 dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
             });
-            __syncthreads();
+            if (KPB == 1 || (k % KPB) == KPB - 1 || k == nk - 1) __syncthreads();
             ++k;
         }
         __syncthreads();
@@ -279,15 +280,17 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
         __syncthreads();
         SR3_FRAG_READ(0, 0, 0)
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
+            const int cur = ((kt / KPB) & 1) * KPB + (kt % KPB);          // LDS slot of tile kt
+            const int nxt = (((kt + 1) / KPB) & 1) * KPB + ((kt + 1) % KPB);
+            const bool sync = KPB == 1 || (kt % KPB) == KPB - 1 || kt == nk - 1;
             SR3_FRAG_READ(1, cur, 1)
             SR3_FRAG_MMA(0)
             SR3_FRAG_READ(0, cur, 2)
             SR3_FRAG_MMA(1)
             SR3_FRAG_READ(1, cur, 3)
             SR3_FRAG_MMA(0)
-            __syncthreads();                   // every read of tile kt has been issued and waited
-            SR3_FRAG_READ(0, cur ^ 1, 0)       // next tile (stale data after the last one: unused)
+            if (sync) __syncthreads();         // every read of this stage has been issued and waited
+            SR3_FRAG_READ(0, nxt, 0)           // next tile (stale data after the last one: unused)
             SR3_FRAG_MMA(1)
         }
 #undef SR3_FRAG_READ
@@ -326,11 +329,13 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
         __syncthreads();
         SR3_FRAG_READ(0, 0, 0)
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
+            const int cur = ((kt / KPB) & 1) * KPB + (kt % KPB);
+            const int nxt = (((kt + 1) / KPB) & 1) * KPB + ((kt + 1) % KPB);
+            const bool sync = KPB == 1 || (kt % KPB) == KPB - 1 || kt == nk - 1;
             SR3_FRAG_READ(1, cur, 1)
             SR3_FRAG_MMA(0)
-            __syncthreads();                   // every read of tile kt has been issued and waited
-            SR3_FRAG_READ(0, cur ^ 1, 0)
+            if (sync) __syncthreads();         // every read of this stage has been issued and waited
+            SR3_FRAG_READ(0, nxt, 0)
             SR3_FRAG_MMA(1)
         }
 #undef SR3_FRAG_READ
@@ -388,11 +393,11 @@ __global__ __launch_bounds__(512, ((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1
     if (p.stats != nullptr) __syncthreads();
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
-void launch_inst(const ConvParams &p, hipStream_t s) {
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int KPB>
+void launch_inst2(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t lds = ((size_t)2 * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
-    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2, PREC>;
+    constexpr size_t lds = ((size_t)2 * KPB * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
+    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2, PREC, KPB>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -401,6 +406,13 @@ void launch_inst(const ConvParams &p, hipStream_t s) {
     const int M = p.B * p.Hout * p.Wout;
     const int tilesM = (M + BM - 1) / BM, tilesN = (p.out.C + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), lds, s, p);
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
+void launch_inst(const ConvParams &p, hipStream_t s) {
+    // KPB = 2 (two K-tiles per barrier, one block per CU) measured slower in both precisions
+    // (profiles/README.md), so only KPB = 1 is instantiated
+    launch_inst2<BM, BN, WGM, WGN, KS, UP2, PREC, 1>(p, s);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -423,6 +435,8 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
 // (32-bit byte offsets in the DMA addressing).
 // tile choice: 0 = 128x32, 1 = 128x64, 2 = 64x64, 3 = 128x128
 static int conv_tile_choice(long M, int Cout) {
+    static const char *force = getenv("SR3_CONV_TILE");   // experiments only
+    if (force) return atoi(force);
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
     const long want = 512;  // 256 CUs x 2 resident blocks
     if (Cout <= 32) return 0;

@@ -493,6 +493,7 @@ __global__ void init_state_kernel(const TDesc state, int xoff, int C, const floa
 __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW, NCHW order
     if (i >= total) return;
+    const StepArgs sa = *u.args;
     const int HW = u.state.H * u.state.W;
     const int pp = (int)(i % HW);
     const size_t nc = i / HW;
@@ -502,16 +503,16 @@ __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     const size_t si = u.state.pix(n, y, xx) * u.state.C + u.xoff + c;
     const float x = u.state.p[si];
     const float e = u.eps.p[u.eps.pix(n, y, xx) * u.eps.C + c];
-    float x0 = __fsub_rn(__fmul_rn(u.a, x), __fmul_rn(u.b, e));
+    float x0 = __fsub_rn(__fmul_rn(sa.a, x), __fmul_rn(sa.b, e));
     x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-    float v = __fadd_rn(__fmul_rn(u.c1, x0), __fmul_rn(u.c2, x));
-    if (u.sigma != 0.f) {
-        const float z = u.noise ? u.noise[i]
-                                : philox_normal(u.seed, u.image_offset + n, u.draw, (uint32_t)(c * HW + pp));
-        v = __fadd_rn(v, __fmul_rn(z, u.sigma));
+    float v = __fadd_rn(__fmul_rn(sa.c1, x0), __fmul_rn(sa.c2, x));
+    if (sa.sigma != 0.f) {
+        const float z = sa.noise ? sa.noise[i]
+                                 : philox_normal(sa.seed, sa.image_offset + n, sa.draw, (uint32_t)(c * HW + pp));
+        v = __fadd_rn(v, __fmul_rn(z, sa.sigma));
     }
     u.state.p[si] = v;
-    if (u.frame) u.frame[i] = v;
+    if (sa.frame) sa.frame[i] = v;
 }
 
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }

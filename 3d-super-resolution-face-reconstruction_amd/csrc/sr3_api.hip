@@ -119,7 +119,7 @@ struct sr3_ctx {
     TDesc x0;                   // [B][H+2][W+2][in_pad]: cond ‖ x ‖ zero pad (UNet input = sampler state)
     TDesc eps;                  // [B][H][W][out_channel]
     TDesc final_act;            // activated input of final_conv
-    float *rbuf = nullptr, *qkvb = nullptr, *aob = nullptr;
+    float *qkvb = nullptr, *aob = nullptr;
     float *gscale = nullptr, *gshift = nullptr, *gpart = nullptr;
     float *temb = nullptr, *cbias = nullptr;
 
@@ -131,6 +131,14 @@ struct sr3_ctx {
     // sampler state
     uint64_t seed = 0, image_offset = 0;
     bool sampling = false;
+    // per-step arguments: pinned host ring -> device struct (async copy before every step)
+    static constexpr int kRing = 256;
+    StepArgs *h_ring = nullptr, *d_step = nullptr;
+    uint64_t step_count = 0;
+    // one p_sample step captured as a hipGraph (per precision); rebuilt when the workspace changes
+    hipGraphExec_t step_graph[2] = {nullptr, nullptr};
+    int graph_warm[2] = {0, 0};
+    bool no_graph = false;
 
     // profiling
     bool prof = false;
@@ -374,6 +382,8 @@ struct ShapePool {
     }
 };
 
+void drop_graphs(sr3_ctx *c);
+
 int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     if (c->arena && c->wB == B && c->wH == H && c->wW == W) return 0;
     const sr3_unet_cfg &g = c->cfg;
@@ -386,6 +396,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         HIP_OK(hipFree(c->arena));
         c->arena = nullptr;
     }
+    drop_graphs(c);
     // dry run over the graph for sizes
     Carver cv;
     ShapePool acts, h1s, raws;
@@ -393,7 +404,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
     std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm);
     std::vector<int> s_slices(nm, 0);
-    uint64_t max_rb = 0, max_qkv = 0, max_ao = 0;
+    uint64_t max_qkv = 0, max_ao = 0;
     int h = H, w = W;
     int cur_c = c->in_pad;
     std::vector<int> feat_c;
@@ -409,8 +420,6 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             a2_off[i] = acts.get(cv, B, oc, h, w);
             h1_off[i] = h1s.get(cv, B, oc, h, w);
             if (m.rb.has_res) raw_off[i] = raws.get(cv, B, m.rb.cin, h, w);
-            const uint64_t n = (uint64_t)B * (h + 2) * (w + 2) * oc;
-            if (n > max_rb) max_rb = n;
             if (m.rb.attn) {
                 const uint64_t nu = (uint64_t)B * h * w * oc;
                 if (3 * nu > max_qkv) max_qkv = 3 * nu;
@@ -456,7 +465,6 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t o_fa = acts.get(cv, B, c->final_gn.C, H, W);
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t o_x0 = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
-    const uint64_t o_r = cv.take(max_rb);
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
     const uint64_t o_gp = cv.take(gn_workspace_floats(B, c->c_max));
@@ -495,7 +503,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     c->x0 = desc(o_x0, c->in_pad, H, W, 1);
     c->eps = desc(o_eps, g.out_channel, H, W, 0);
     c->final_act = desc(o_fa, c->final_gn.C, H, W, 1);
-    c->rbuf = at(o_r); c->qkvb = at(o_qkv); c->aob = at(o_ao);
+    c->qkvb = at(o_qkv); c->aob = at(o_ao);
     c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
     c->temb = at(o_te); c->cbias = at(o_cb);
     c->wB = B; c->wH = H; c->wW = W;
@@ -673,26 +681,70 @@ int check_ready(sr3_ctx *c) {
     return prepare_fused(c);
 }
 
-int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
-    if (!c->sampling) return fail("sr3_sample_step before sr3_sample_begin");
-    if (t < 0 || t >= c->T) return fail("step t=%d outside schedule of %d steps", t, c->T);
+void drop_graphs(sr3_ctx *c) {
+    for (int i = 0; i < 2; ++i) {
+        if (c->step_graph[i]) (void)hipGraphExecDestroy(c->step_graph[i]);
+        c->step_graph[i] = nullptr;
+        c->graph_warm[i] = 0;
+    }
+}
+
+// the launches of one p_sample step (embedding, UNet body, DDPM update); every per-step value is
+// read from c->d_step, so the sequence is identical for every t
+void enqueue_step(sr3_ctx *c) {
     const int B = c->wB, H = c->wH, W = c->wW;
     // noise_level = float32(sqrt_alphas_cumprod_prev[t+1]) repeated over the batch (diffusion.py:166-167)
-    run_embed(c, c->d_nl + (t + 1), 0, B);
+    run_embed(c, &c->d_step->nl, 0, B);
     run_unet_body(c, B, H, W);
     UpdateParams u;
     u.state = c->x0; u.C = c->cfg.out_channel;
     u.xoff = c->cfg.in_channel - c->cfg.out_channel;
     u.eps = c->eps;
-    u.noise = noise_slab;
-    u.a = c->s_a[t]; u.b = c->s_b[t]; u.c1 = c->s_c1[t]; u.c2 = c->s_c2[t];
-    u.sigma = t > 0 ? expf(0.5f * c->s_lv[t]) : 0.f;
-    u.seed = c->seed; u.image_offset = c->image_offset;
-    u.draw = (uint32_t)(c->T - t);
-    u.frame = frame;
+    u.args = c->d_step;
     c->pbegin(F_MISC);
     launch_ddpm_update(u, B, c->stream);
     c->pend();
+}
+
+int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
+    if (!c->sampling) return fail("sr3_sample_step before sr3_sample_begin");
+    if (t < 0 || t >= c->T) return fail("step t=%d outside schedule of %d steps", t, c->T);
+    if (!c->h_ring) {
+        HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&c->h_ring), sizeof(StepArgs) * sr3_ctx::kRing, hipHostMallocDefault));
+        HIP_OK(hipMalloc(&c->d_step, sizeof(StepArgs)));
+    }
+    // the host may run far ahead of the GPU: never reuse a ring slot that may still be pending
+    if (c->step_count && (c->step_count % (sr3_ctx::kRing / 2)) == 0) HIP_OK(hipStreamSynchronize(c->stream));
+    StepArgs &sa = c->h_ring[c->step_count % sr3_ctx::kRing];
+    ++c->step_count;
+    sa.nl = c->s_nl[t + 1];
+    sa.a = c->s_a[t]; sa.b = c->s_b[t]; sa.c1 = c->s_c1[t]; sa.c2 = c->s_c2[t];
+    sa.sigma = t > 0 ? expf(0.5f * c->s_lv[t]) : 0.f;
+    sa.draw = (uint32_t)(c->T - t); sa.pad_ = 0;
+    sa.noise = noise_slab; sa.frame = frame;
+    sa.seed = c->seed; sa.image_offset = c->image_offset;
+    HIP_OK(hipMemcpyAsync(c->d_step, &sa, sizeof(StepArgs), hipMemcpyHostToDevice, c->stream));
+
+    const int g = c->prec;
+    if (c->prof || c->no_graph) {
+        enqueue_step(c);
+        return 0;
+    }
+    if (!c->step_graph[g]) {
+        if (c->graph_warm[g] < 1) {          // first step runs eagerly (one-time function attributes)
+            ++c->graph_warm[g];
+            enqueue_step(c);
+            return 0;
+        }
+        hipGraph_t graph = nullptr;
+        HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_step(c);
+        HIP_OK(hipStreamEndCapture(c->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&c->step_graph[g], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    HIP_OK(hipGraphLaunch(c->step_graph[g], c->stream));
     return 0;
 }
 
@@ -725,6 +777,7 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
     c->cfg = *cfg;
     c->device = device;
     if (const char *e = getenv("SR3_NO_FUSED_STATS")) c->no_fused_stats = atoi(e) != 0;
+    if (const char *e = getenv("SR3_NO_GRAPH")) c->no_graph = atoi(e) != 0;
     if (build_graph(c)) { delete c; return -1; }
     if (alloc_weights(c)) { sr3_destroy(c); return -1; }
     if (hipStreamCreate(&c->own_stream) != hipSuccess) { sr3_destroy(c); return fail("hipStreamCreate failed"); }
@@ -747,6 +800,9 @@ void sr3_destroy(sr3_ctx *c) {
     if (c->nfb) (void)hipFree(c->nfb);
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_nl) (void)hipFree(c->d_nl);
+    drop_graphs(c);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    if (c->d_step) (void)hipFree(c->d_step);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -105,15 +105,21 @@ void launch_noise_embed(const EmbedParams &p, int B, hipStream_t s);
 void launch_nchw_to_nhwc(const float *in, int B, int C, const TDesc &dst, int coff, hipStream_t s);
 // channels [coff, coff+C) of src -> NCHW
 void launch_nhwc_to_nchw(const TDesc &src, int coff, int B, int C, float *out, hipStream_t s);
+// Per-step values live in device memory (written by a tiny async copy before every step), so the
+// kernel arguments of a step never change and the whole step can be replayed as one hipGraph.
+struct StepArgs {
+    float nl;                   // noise level fed to the embedding (diffusion.py:166-167)
+    float a, b, c1, c2, sigma;  // recip, recipm1, coef1, coef2, exp(0.5*logvar) (0 at t == 0)
+    uint32_t draw, pad_;
+    const float *noise;         // NCHW [B][C][HW] or null -> Philox
+    float *frame;               // NCHW [B][C][HW] or null: copy of the updated image
+    uint64_t seed, image_offset;
+};
 struct UpdateParams {
     TDesc state;        // x lives in channels [xoff, xoff+C)
     int xoff, C;        // C = image channels (3)
     TDesc eps;          // eps.C >= C
-    const float *noise; // NCHW [B][C][HW] or null -> Philox
-    float a, b, c1, c2, sigma; // recip, recipm1, coef1, coef2, exp(0.5*logvar) (0 at t == 0)
-    uint64_t seed, image_offset;
-    uint32_t draw;
-    float *frame;       // NCHW [B][C][HW] or null: copy of the updated image
+    const StepArgs *args;
 };
 void launch_ddpm_update(const UpdateParams &p, int B, hipStream_t s);
 // x <- noise (NCHW buffer or Philox draw 0) into state channels
