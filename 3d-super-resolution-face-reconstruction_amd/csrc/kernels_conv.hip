@@ -58,6 +58,15 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
+// producer side of a pipeline barrier: wait until at most N of this wave's LDS-DMA instructions
+// are still in flight, then the workgroup barrier. A raw s_barrier is used because __syncthreads()
+// would drain every outstanding DMA (vmcnt(0)).
+template <int N>
+__device__ __forceinline__ void producer_sync() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
     // 64 lanes x 16 B -> 1 KiB at lds_wave_base (wave-uniform) + lane * 16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -66,9 +75,10 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 
 // KS: 1 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into the gather
 // PREC 0: exact f32 (v_mfma_f32_32x32x2_f32); PREC 1: split-f16, 3 x v_mfma_f32_32x32x16_f16
-// KPB: K-tiles per barrier interval (a pipeline stage holds KPB tiles); KPB 2 = one block per CU
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int KPB>
-__global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p) {
+// NS: LDS pipeline stages (power of two or 3); the DMA of tile k+NS-1 is issued while tile k is
+// multiplied, so NS-2 tiles stay in flight across a barrier (counted vmcnt + raw s_barrier)
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int NS>
+__global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [2 stages][A: BM rows | B: BN rows][32 floats], then per-row tables for the epilogue
-    int *rowpix = reinterpret_cast<int *>(smem + 2 * KPB * STAGE);   // [BM] padded output pixel index
+    int *rowpix = reinterpret_cast<int *>(smem + NS * STAGE);   // [BM] padded output pixel index
     int *rowimg = rowpix + BM;                                  // [BM] image index
 
     const int C0 = p.in0.C, C1 = p.in1.p ? p.in1.C : 0;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
             static_for<TAPS>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int dy = tap / KS, dx = tap % KS;
-                float *Ad = smem + (((k / KPB) & 1) * KPB + (k % KPB)) * STAGE + w * 256;
+                float *Ad = smem + (k % NS) * STAGE + w * 256;
                 float *Bd = Ad + BM * ROWF;
                 if (!(p.dbg & 1) || k == 0) {
                     const char *ab = UP2 ? abase : abase + (size_t)(dy * Wp + dx) * Cs * 4;
@@ -196,13 +206,13 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
                         dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
                     });
                 }
-                if (KPB == 1 || (k % KPB) == KPB - 1 || k == nk - 1) __syncthreads();
+                if (k >= NS - 2) producer_sync<(NS - 2) * (AR + BR)>();
                 ++k;
             });
         }
         // fused 1x1 term: K-steps over the channels of in2, read at the output pixel
         for (int c0 = 0; c0 < C2; c0 += BK) {
-            float *Ad = smem + (((k / KPB) & 1) * KPB + (k % KPB)) * STAGE + w * 256;
+            float *Ad = smem + (k % NS) * STAGE + w * 256;
             float *Bd = Ad + BM * ROWF;
             const char *ab = reinterpret_cast<const char *>(p.in2.p + c0);
             const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
@@ -214,9 +224,14 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
                 constexpr int i = decltype(ic)::value;
                 dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
             });
-            if (KPB == 1 || (k % KPB) == KPB - 1 || k == nk - 1) __syncthreads();
+            if (k >= NS - 2) producer_sync<(NS - 2) * (AR + BR)>();
             ++k;
         }
+        // drain: the last NS-2 tiles are still in flight
+        static_for<NS - 2>([&](auto rc) {
+            constexpr int r = NS - 3 - decltype(rc)::value;     // NS-3 ... 0 tiles may stay in flight
+            if (r < nk) producer_sync<r * (AR + BR)>();
+        });
         __syncthreads();
         if (p.stats == nullptr) return;
         // fused GroupNorm statistics: the consumers leave per-(wave row, lane half, column) sums in
@@ -280,9 +295,8 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
         __syncthreads();
         SR3_FRAG_READ(0, 0, 0)
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = ((kt / KPB) & 1) * KPB + (kt % KPB);          // LDS slot of tile kt
-            const int nxt = (((kt + 1) / KPB) & 1) * KPB + ((kt + 1) % KPB);
-            const bool sync = KPB == 1 || (kt % KPB) == KPB - 1 || kt == nk - 1;
+            const int cur = kt % NS, nxt = (kt + 1) % NS;                  // LDS stage of tile kt / kt+1
+            constexpr bool sync = true;
             SR3_FRAG_READ(1, cur, 1)
             SR3_FRAG_MMA(0)
             SR3_FRAG_READ(0, cur, 2)
@@ -329,9 +343,8 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
         __syncthreads();
         SR3_FRAG_READ(0, 0, 0)
         for (int kt = 0; kt < nk; ++kt) {
-            const int cur = ((kt / KPB) & 1) * KPB + (kt % KPB);
-            const int nxt = (((kt + 1) / KPB) & 1) * KPB + ((kt + 1) % KPB);
-            const bool sync = KPB == 1 || (kt % KPB) == KPB - 1 || kt == nk - 1;
+            const int cur = kt % NS, nxt = (kt + 1) % NS;
+            constexpr bool sync = true;
             SR3_FRAG_READ(1, cur, 1)
             SR3_FRAG_MMA(0)
             if (sync) __syncthreads();         // every read of this stage has been issued and waited
@@ -393,11 +406,11 @@ __global__ __launch_bounds__(512, KPB == 2 ? 2 : (((BM + BN) * ROWF * 8 + 8 * BM
     if (p.stats != nullptr) __syncthreads();
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int KPB>
+template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int NS>
 void launch_inst2(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t lds = ((size_t)2 * KPB * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
-    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2, PREC, KPB>;
+    constexpr size_t lds = ((size_t)NS * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
+    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2, PREC, NS>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -410,9 +423,11 @@ void launch_inst2(const ConvParams &p, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
 void launch_inst(const ConvParams &p, hipStream_t s) {
-    // KPB = 2 (two K-tiles per barrier, one block per CU) measured slower in both precisions
-    // (profiles/README.md), so only KPB = 1 is instantiated
-    launch_inst2<BM, BN, WGM, WGN, KS, UP2, PREC, 1>(p, s);
+    // stages per tile shape (A/B in profiles/README.md): the 64x64 tile is used where few blocks
+    // are resident (small M), so it gets a 4-deep ring (2 blocks/CU); the larger tiles run 2-3
+    // blocks per CU with 2 stages (3 stages x 2 blocks measured the same or slower)
+    constexpr int NS = (BM + BN) <= 128 ? 4 : 2;
+    launch_inst2<BM, BN, WGM, WGN, KS, UP2, PREC, NS>(p, s);
 }
 
 template <int BM, int BN, int WGM, int WGN>
