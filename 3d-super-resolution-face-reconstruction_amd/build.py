@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsr3hip.so")
-SOURCES = ["sr3_api.hip", "kernels_conv.hip", "kernels_misc.hip"]
+SOURCES = ["sr3_api.hip", "kernels_conv.hip", "kernels_misc.hip", "kernels_pre.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -53,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r
 
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

@@ -1203,6 +1203,39 @@ int sr3_op_nhwc_to_nchw(sr3_ctx *c, const float *in_dev, int B, int C, int H, in
     return 0;
 }
 
+// ---- pre-processing ----------------------------------------------------------------------------
+int sr3_preprocess_bicubic(sr3_ctx *c, const uint8_t *in_hwc_dev, int B, int Hin, int Win, int Hout, int Wout,
+                           float *out_nchw_dev, uint8_t *out_u8_hwc_dev) {
+    if (!c || !in_hwc_dev || !out_nchw_dev) return fail("sr3_preprocess_bicubic: null argument");
+    if (B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return fail("sr3_preprocess_bicubic: bad size");
+    HIP_OK(hipSetDevice(c->device));
+    std::vector<int> bh, kh, bv, kv;
+    int ksh = 0, ksv = 0;
+    if (Wout != Win) ksh = bicubic_coeffs(Win, Wout, bh, kh);
+    if (Hout != Hin) ksv = bicubic_coeffs(Hin, Hout, bv, kv);
+    const size_t nt = (bh.size() + kh.size() + bv.size() + kv.size()) * sizeof(int);
+    const size_t ntmp = ksh ? (size_t)B * Hin * Wout * 3 : 0;
+    char *buf = nullptr;
+    HIP_OK(hipMalloc(&buf, nt + ntmp + 16));
+    int *d_bh = reinterpret_cast<int *>(buf), *d_kh = d_bh + bh.size(), *d_bv = d_kh + kh.size(), *d_kv = d_bv + bv.size();
+    uint8_t *tmp = reinterpret_cast<uint8_t *>(d_kv + kv.size());
+    if (ksh) {
+        HIP_OK(hipMemcpyAsync(d_bh, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_kh, kh.data(), kh.size() * 4, hipMemcpyHostToDevice, c->stream));
+        launch_resample_h(in_hwc_dev, B, Hin, Win, Wout, d_bh, d_kh, ksh, tmp, c->stream);
+    }
+    if (ksv) {
+        HIP_OK(hipMemcpyAsync(d_bv, bv.data(), bv.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(d_kv, kv.data(), kv.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    launch_resample_v(ksh ? tmp : in_hwc_dev, B, Hin, Hout, Wout, ksv ? d_bv : nullptr, d_kv, ksv, out_nchw_dev,
+                      out_u8_hwc_dev, c->stream);
+    HIP_OK(hipStreamSynchronize(c->stream));   // the coefficient vectors and buf go out of scope
+    HIP_OK(hipFree(buf));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 // ---- device memory helpers ---------------------------------------------------------------------
 int sr3_dev_malloc(sr3_ctx *c, uint64_t bytes, void **out_dev) {
     if (!c || !out_dev) return fail("null argument");

@@ -128,4 +128,15 @@ void launch_init_state(const TDesc &state, int xoff, int C, const float *noise, 
 void launch_philox_normal(uint64_t seed, uint64_t image, uint32_t draw, int n, float *out,
                           hipStream_t s);
 
+// ---- pre-processing: PIL-exact 8-bit bicubic resize -> sampler input tensor (kernels_pre.hip) ----
+} // namespace sr3
+#include <vector>
+namespace sr3 {
+int bicubic_coeffs(int in_size, int out_size, std::vector<int> &bounds, std::vector<int> &kk);   // returns ksize
+void launch_resample_h(const uint8_t *in, int B, int H, int Win, int Wout, const int *bounds, const int *kk,
+                       int ksize, uint8_t *out, hipStream_t s);
+// bounds == nullptr: no vertical resize (Hin == Hout), only the tensor conversion
+void launch_resample_v(const uint8_t *in, int B, int Hin, int Hout, int W, const int *bounds, const int *kk,
+                       int ksize, float *out_nchw, uint8_t *out_u8, hipStream_t s);
+
 } // namespace sr3

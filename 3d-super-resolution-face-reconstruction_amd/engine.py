@@ -180,6 +180,25 @@ class Engine:
         _lib.check(self.lib.sr3_philox_normal(self.ctx, seed, image, draw, n, buf.ptr))
         return buf.download()
 
+    # ---- pre-processing ---------------------------------------------------------------------
+    def preprocess_bicubic(self, in_ptr: int, B: int, Hin: int, Win: int, Hout: int, Wout: int,
+                           out_ptr: int, out_u8_ptr: Optional[int] = None) -> None:
+        """uint8 HWC device images -> PIL-exact bicubic -> fp32 NCHW [-1,1] (sr3_preprocess_bicubic)."""
+        _lib.check(self.lib.sr3_preprocess_bicubic(self.ctx, in_ptr, B, Hin, Win, Hout, Wout, out_ptr,
+                                                   out_u8_ptr or None))
+
+    def preprocess_bicubic_np(self, img_u8: np.ndarray, Hout: int, Wout: int):
+        """numpy convenience: [B,H,W,3] uint8 -> (fp32 [B,3,Hout,Wout], uint8 [B,Hout,Wout,3])."""
+        a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        B, H, W, _ = a.shape
+        nin, nout = a.size, B * Hout * Wout * 3
+        din, dout, du8 = self.buffer((nin + 3) // 4), self.buffer(nout), self.buffer((nout + 3) // 4)
+        _lib.check(self.lib.sr3_memcpy_h2d(self.ctx, din.ptr, a.ctypes.data, nin))
+        self.preprocess_bicubic(din.ptr, B, H, W, Hout, Wout, dout.ptr, du8.ptr)
+        u8 = np.empty(nout, dtype=np.uint8)
+        _lib.check(self.lib.sr3_memcpy_d2h(self.ctx, u8.ctypes.data, du8.ptr, nout))
+        return dout.download((B, 3, Hout, Wout)), u8.reshape(B, Hout, Wout, 3)
+
     # ---- measurement ------------------------------------------------------------------------
     def profile_enable(self, on: bool):
         _lib.check(self.lib.sr3_profile_enable(self.ctx, 1 if on else 0))

@@ -173,6 +173,15 @@ int sr3_op_nchw_to_nhwc(sr3_ctx *ctx, const float *in_dev, int B, int C, int H, 
 int sr3_op_nhwc_to_nchw(sr3_ctx *ctx, const float *in_dev, int B, int C, int H, int W,
                         float *out_dev);
 
+/* ---- pre-processing in front of the sampler ------------------------------------------------- */
+
+/* replaces: the PIL 8-bit bicubic upsample that builds the conditioning image
+ * (datasets/tool/prepare_data.py:24-47: Image.resize(size, BICUBIC)) followed by ToTensor and
+ * x*2-1 (datasets/util.py:76-83). in: uint8 [B,Hin,Win,3] (HWC, RGB); out: fp32 [B,3,Hout,Wout]
+ * in [-1,1]; out_u8 (optional) the resized uint8 image. Bit-exact with Pillow 12.2. Synchronous. */
+int sr3_preprocess_bicubic(sr3_ctx *ctx, const uint8_t *in_hwc_dev, int B, int Hin, int Win, int Hout,
+                           int Wout, float *out_nchw_dev, uint8_t *out_u8_hwc_dev);
+
 /* ---- device memory helpers (so hosts without torch can drive the library) ---------------- */
 int sr3_dev_malloc(sr3_ctx *ctx, uint64_t bytes, void **out_dev);
 int sr3_dev_free(sr3_ctx *ctx, void *dev);

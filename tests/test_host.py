@@ -136,3 +136,29 @@ def test_philox_twin_known_answer():
     f = 0xFFFFFFFF
     o = philox.philox4x32_10(f, f, f, f, f, f)
     assert [int(x) for x in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+def test_ssim_matches_independent_scipy_evaluation():
+    """validation.ssim (numpy restatement of core/metrics.py:84-104) against scipy's correlate."""
+    from scipy.ndimage import correlate
+    val = pkg("validation")
+    rs = np.random.RandomState(0)
+    a = rs.randint(0, 256, (40, 48)).astype(np.uint8)
+    b = np.clip(a.astype(int) + rs.randint(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    k = val.gaussian_kernel(11, 1.5)
+    assert abs(k.sum() - 1) < 1e-12 and k.argmax() == 5
+    win = np.outer(k, k)
+
+    def f(x):
+        return correlate(x.astype(np.float64), win, mode="mirror")[5:-5, 5:-5]   # filter2D default border, cropped
+    C1, C2 = 6.5025, 58.5225
+    A, B = a.astype(np.float64), b.astype(np.float64)
+    mu1, mu2 = f(A), f(B)
+    ref = (((2 * mu1 * mu2 + C1) * (2 * (f(A * B) - mu1 * mu2) + C2)) /
+           ((mu1 ** 2 + mu2 ** 2 + C1) * (f(A * A) - mu1 ** 2 + f(B * B) - mu2 ** 2 + C2))).mean()
+    assert abs(val.ssim(a, b) - ref) < 1e-10
+    assert abs(val.ssim(a, a) - 1.0) < 1e-12
+    rgb_a, rgb_b = np.stack([a, b, a], -1), np.stack([b, b, a], -1)
+    assert abs(val.calculate_ssim(rgb_a, rgb_b) - (val.ssim(a, b) + 2) / 3) < 1e-12
+    with pytest.raises(ValueError):
+        val.calculate_ssim(a, b[:-1])

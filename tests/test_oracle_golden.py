@@ -61,3 +61,16 @@ def test_sampler_matches_reference(name):
     assert ret.shape == g["ret_img"].shape
     np.testing.assert_allclose(ret, g["ret_img"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(final[-1], g["last"], atol=1e-4, rtol=0)
+
+
+def test_pil_bicubic_restatement_bit_exact():
+    """oracle/pil_bicubic.py against Pillow's own output (tests/golden/make_golden_preproc.py)."""
+    import pil_bicubic as pb
+    g = load_golden("preproc_bicubic.npz")
+    for i, (a, b) in enumerate(g["meta"]["cases"]):
+        np.testing.assert_array_equal(pb.resize_u8(g[f"in{i}"], b, b), g[f"out{i}"], err_msg=f"{a}->{b}")
+    lr = pb.resize_u8(g["chain_hr"], 16, 16)
+    np.testing.assert_array_equal(lr, g["chain_lr"])
+    np.testing.assert_array_equal(pb.resize_u8(lr, 128, 128), g["chain_sr"])
+    t = pb.to_tensor_pm1(g["chain_sr"])
+    assert t.shape == (3, 128, 128) and t.dtype == np.float32 and t.min() >= -1 and t.max() <= 1
