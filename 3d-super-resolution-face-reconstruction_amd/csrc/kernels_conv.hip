@@ -109,8 +109,13 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
     constexpr int TAPS = KS * KS;
-    const int C2 = p.in2.p ? p.in2.C : 0;          // fused 1x1 term (res_conv)
-    const int nk = TAPS * (Cin / BK) + C2 / BK;
+    // split-K: this block reduces chunks [cb, ce) of the input channels (all taps); the fused 1x1
+    // term belongs to the last split
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int nchunk = Cin / BK;
+    const int cb = (int)((long)nchunk * split / nsplit) * BK, ce = (int)((long)nchunk * (split + 1) / nsplit) * BK;
+    const int C2 = (p.in2.p && split == nsplit - 1) ? p.in2.C : 0;          // fused 1x1 term (res_conv)
+    const int nk = TAPS * ((ce - cb) / BK) + C2 / BK;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             constexpr int i = decltype(ic)::value;
             const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
             vB[i] = (unsigned)n * (unsigned)Cin * 4u + schunk16;
-            vB2[i] = (unsigned)n * (unsigned)C2 * 4u + schunk16;
+            vB2[i] = (unsigned)n * (unsigned)(p.in2.p ? p.in2.C : 0) * 4u + schunk16;
         });
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             const int n = m / HWo;
             const int rem = m - n * HWo;
             const int oy = rem / p.Wout;
-            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)C2 * 4u + schunk16 : 0u;
+            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)p.in2.C * 4u + schunk16 : 0u;
         });
         const size_t tapstride = (size_t)Cout * Cin;   // floats between taps of the packed weights
 
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         // other stage (free since the barrier that ended step kt-1); the barrier's implied
         // vmcnt(0) makes the DMA data visible before anybody reads it.
         int k = 0;
-        for (int c0 = 0; c0 < Cin; c0 += BK) {
+        for (int c0 = cb; c0 < ce; c0 += BK) {
             const bool first = c0 < C0;
             const int Cs = first ? C0 : C1;
             const char *abase = reinterpret_cast<const char *>((first ? p.in0.p : p.in1.p) + (first ? c0 : c0 - C0));
@@ -361,6 +366,22 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= p.w_unscale;
     }
 
+    if (nsplit > 1) {
+        // split-K: raw partial sums to part[split][m][n]; the reduce kernel finishes the epilogue
+        float *pp = p.part + (size_t)split * M * Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * WN + ni * 32 + li;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M && n < Cout) pp[(size_t)m * Cout + n] = acc[mi][ni][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue: bias + FeatureWiseAffine channel bias + residual, stores into the padded
     // output. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Processed 4 accumulator registers (4 consecutive rows) at a time to keep registers low.
@@ -418,7 +439,7 @@ void launch_inst2(const ConvParams &p, hipStream_t s) {
     }
     const int M = p.B * p.Hout * p.Wout;
     const int tilesM = (M + BM - 1) / BM, tilesN = (p.out.C + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN, p.splits > 1 ? p.splits : 1), dim3(512), lds, s, p);
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
@@ -448,6 +469,29 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
 // Preconditions (checked by the callers in sr3_api.hip): channels multiples of 32, 3x3 inputs
 // zero-bordered (pad 1), up2 only with ks 3 / stride 1 / single input, every tensor < 4 GiB
 // (32-bit byte offsets in the DMA addressing).
+// split-K second pass: out = sum_s part[s] + bias + FeatureWiseAffine bias + residual
+__global__ void conv_splitk_reduce_kernel(const ConvParams p, int M, int HWo) {
+    const int Cout = p.out.C, C4 = Cout >> 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * C4) return;
+    const int m = (int)(i / C4), n = (int)(i - (size_t)m * C4) << 2;
+    float4 a = *reinterpret_cast<const float4 *>(p.part + (size_t)m * Cout + n);
+    for (int s = 1; s < p.splits; ++s) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.part + ((size_t)s * M + m) * Cout + n);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int img = m / HWo, rem = m - img * HWo, oy = rem / p.Wout;
+    const size_t o = p.out.pix(img, oy, rem - oy * p.Wout) * Cout + n;
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (p.bias) v[j] += p.bias[n + j];
+        if (p.chan_bias) v[j] += p.chan_bias[(size_t)img * p.chan_bias_stride + n + j];
+        if (p.resid.p) v[j] += p.resid.p[o + j];
+        p.out.p[o + j] = v[j];
+    }
+}
+
 // tile choice: 0 = 128x32, 1 = 128x64, 2 = 64x64, 3 = 128x128
 static int conv_tile_choice(long M, int Cout) {
     static const char *force = getenv("SR3_CONV_TILE");   // experiments only
@@ -462,15 +506,35 @@ static int conv_tile_choice(long M, int Cout) {
 
 int conv_tile_m(long M, int Cout) { return conv_tile_choice(M, Cout) == 2 ? 64 : 128; }
 
+int conv_splits(long M, int Cout, int Cin) {
+    static const int off = getenv("SR3_NO_SPLITK") ? atoi(getenv("SR3_NO_SPLITK")) : 0;
+    if (off || (Cout & 3)) return 1;
+    static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
+    const int t = conv_tile_choice(M, Cout);
+    const long tiles = ((M + bm[t] - 1) / bm[t]) * ((Cout + bn[t] - 1) / bn[t]);
+    const int nchunk = Cin / BK;
+    if (tiles >= 128 || nchunk < 4) return 1;
+    int s = 2;
+    while (s * 2 <= nchunk / 2 && tiles * s * 2 <= 512 && s < 16) s *= 2;
+    return s;
+}
+
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     ConvParams p = p_in;
     if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
     const long M = (long)p.B * p.Hout * p.Wout;
+    if (p.part == nullptr) p.splits = 1;
+    if (p.splits > 1) p.stats = nullptr;   // the caller falls back to the statistics kernel
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1: launch_cfg<128, 64, 2, 2>(p, s); break;
     case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
     default: launch_cfg<128, 128, 2, 2>(p, s); break;
+    }
+    if (p.splits > 1) {
+        const size_t items = (size_t)M * (p.out.C >> 2);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p,
+                           (int)M, p.Hout * p.Wout);
     }
 }
 

@@ -120,6 +120,7 @@ struct sr3_ctx {
     TDesc eps;                  // [B][H][W][out_channel]
     TDesc final_act;            // activated input of final_conv
     float *qkvb = nullptr, *aob = nullptr;
+    float *part = nullptr;      // split-K partial sums (small-M convs)
     float *gscale = nullptr, *gshift = nullptr, *gpart = nullptr;
     float *temb = nullptr, *cbias = nullptr;
 
@@ -404,7 +405,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
     std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm);
     std::vector<int> s_slices(nm, 0);
-    uint64_t max_qkv = 0, max_ao = 0;
+    uint64_t max_qkv = 0, max_ao = 0, max_part = 0;
     int h = H, w = W;
     int cur_c = c->in_pad;
     std::vector<int> feat_c;
@@ -428,6 +429,19 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             }
         }
         m.oc = oc; m.oh = h; m.ow = w;
+        {   // split-K partial buffer: largest splits * M * Cout over the convs of this module
+            const long Mo = (long)B * h * w;
+            auto want = [&](int cout, int cin) {
+                const int sp = conv_splits(Mo, cout, cin);
+                if (sp > 1) max_part = std::max<uint64_t>(max_part, (uint64_t)sp * Mo * cout);
+            };
+            if (m.kind == M_RES) {
+                want(oc, m.rb.cin); want(oc, oc);
+                if (m.rb.attn) { want(3 * oc, oc); want(oc, oc); }
+            } else {
+                want(oc, m.conv.cin_pad);
+            }
+        }
         {   // fused statistics: every conv writing an [oc, h, w] tensor uses the same tile height
             const int bm = conv_tile_m((long)B * h * w, oc);
             if ((h * w) % bm == 0) {
@@ -466,6 +480,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t o_x0 = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
+    const uint64_t o_part = cv.take(max_part);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
     const uint64_t o_gp = cv.take(gn_workspace_floats(B, c->c_max));
     const uint64_t o_te = cv.take((uint64_t)B * g.inner_channel);
@@ -491,6 +506,15 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             m.st_h1.p = reinterpret_cast<double *>(c->arena + sh_off[i]);
             m.st_out.slices = m.st_rb.slices = m.st_h1.slices = s_slices[i];
             if (!(m.kind == M_RES && m.rb.attn)) m.st_rb = m.st_out;   // rb_out aliases out
+            // a conv that runs split-K does not produce fused statistics: the GroupNorm that
+            // consumes its output falls back to the statistics kernel
+            const long Mo = (long)B * m.oh * m.ow;
+            if (m.kind == M_RES) {
+                if (conv_splits(Mo, m.oc, m.rb.cin) > 1) m.st_h1 = StatsRef();
+                if (conv_splits(Mo, m.oc, m.oc) > 1) { m.st_rb = StatsRef(); m.st_out = StatsRef(); }
+            } else if (conv_splits(Mo, m.oc, m.conv.cin_pad) > 1) {
+                m.st_out = StatsRef();
+            }
         }
         if (m.kind == M_UP || m.kind == M_DOWN) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);
         if (m.kind == M_RES) {
@@ -504,6 +528,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     c->eps = desc(o_eps, g.out_channel, H, W, 0);
     c->final_act = desc(o_fa, c->final_gn.C, H, W, 1);
     c->qkvb = at(o_qkv); c->aob = at(o_ao);
+    c->part = max_part ? at(o_part) : nullptr;
     c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
     c->temb = at(o_te); c->cbias = at(o_cb);
     c->wB = B; c->wH = H; c->wW = W;
@@ -544,6 +569,8 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
     p.resid = resid; p.out = out;
     if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
+    p.splits = conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
+    p.part = c->part;
     if (cv2) {
         p.in2 = in2;
         p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;

@@ -51,11 +51,18 @@ struct ConvParams {
     //         pre-scaled by 2^k (w_unscale = 2^-k is applied to the accumulator in the epilogue).
     int prec = 0;
     float w_unscale = 1.0f;
+    // split-K for small problems (few tiles, deep K): `splits` blocks share one output tile, each
+    // reducing a contiguous range of 32-channel chunks into part[split][M][Cout]; a second kernel
+    // adds the partials and applies the epilogue. splits <= 1: single pass.
+    int splits = 1;
+    float *part = nullptr;
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
 void launch_conv(const ConvParams &p, hipStream_t s);
 // BM of the tile launch_conv will use for this problem (so callers can size / enable fused stats)
 int conv_tile_m(long M, int Cout);
+// number of K-splits launch_conv wants for this problem (1 = none); Cin per tap, multiple of 32
+int conv_splits(long M, int Cout, int Cin);
 // host helper: OIHW -> [tap][Cout][CinPad] (zero pad input channels up to CinPad)
 void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, float *dst);
 // host helper: fp32 packed weights -> split-f16 layout (same byte size), returns the unscale factor
