@@ -74,6 +74,100 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 }
 
 // KS: 1 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into the gather
+// Consumer epilogue shared by the conv kernels: split-K partials, or accumulator + bias +
+// FeatureWiseAffine channel bias + residual into the zero-bordered output, plus the fused
+// GroupNorm statistics (per-column fp64 sums left in LDS for the producer threads).
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int BM, int BN, int WGM, int WGN, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (&acc)[MI][NI], float *smem,
+                                                   const int *rowpix, const int *rowimg, int m0, int n0, int M,
+                                                   int wm, int wn, int li, int lh, int split, int nsplit) {
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    const int Cout = p.out.C;
+    if (nsplit > 1) {
+        // split-K: raw partial sums to part[split][m][n]; the reduce kernel finishes the epilogue
+        float *pp = p.part + (size_t)split * M * Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wn * WN + ni * 32 + li;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M && n < Cout) pp[(size_t)m * Cout + n] = acc[mi][ni][r];
+                }
+        }
+        return;
+    }
+    // processed 4 accumulator registers (4 consecutive rows) at a time to keep registers low
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * WN + ni * 32 + li;
+        const int nc = min(n, Cout - 1);
+        const float bs = p.bias ? p.bias[nc] : 0.f;
+        double st1 = 0.0, st2 = 0.0;       // fused GroupNorm statistics of this lane's column
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int rbase = wm * WM + mi * 32 + 8 * rq + 4 * lh;
+                float add[4];
+                unsigned o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    add[j] = bs;
+                    o[j] = (unsigned)rowpix[rbase + j] * (unsigned)Cout + (unsigned)nc;
+                }
+                if (p.resid.p != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) add[j] += p.resid.p[o[j]];
+                }
+                if (p.chan_bias != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        add[j] += p.chan_bias[(size_t)rowimg[rbase + j] * p.chan_bias_stride + nc];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + rbase + j;
+                    const float v = acc[mi][ni][4 * rq + j] + add[j];
+                    if (m < M && n < Cout) p.out.p[o[j]] = v;
+                    if (p.stats != nullptr) { st1 += (double)v; st2 = fma((double)v, (double)v, st2); }
+                }
+            }
+        }
+        if (p.stats != nullptr)
+            reinterpret_cast<double2 *>(smem)[(wm * 2 + lh) * BN + wn * WN + ni * 32 + li] = make_double2(st1, st2);
+    }
+    if (p.stats != nullptr) __syncthreads();
+}
+
+template <int BM, int BN, int WGM, int WGN, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], float *smem,
+                                              const int *rowpix, const int *rowimg, int m0, int n0, int M, int wm,
+                                              int wn, int li, int lh, int split, int nsplit) {
+    conv_epilogue_impl<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, split, nsplit);
+}
+
+// Producer side of the fused statistics: after the consumers' sums are in LDS, the producer
+// threads add them per column and write this tile's per-channel partials.
+template <int BM, int BN, int WGM>
+__device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const float *smem, int m0, int n0, int HWo) {
+    __syncthreads();
+    const double2 *red = reinterpret_cast<const double2 *>(smem);
+    const int col = threadIdx.x - 256;
+    const int Cout = p.out.C;
+    if (col < BN && n0 + col < Cout) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int j = 0; j < WGM * 2; ++j) { const double2 v = red[j * BN + col]; a += v.x; b += v.y; }
+        const int n = m0 / HWo, slice = (m0 - n * HWo) / BM;
+        double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0 + col) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
 // PREC 0: exact f32 (v_mfma_f32_32x32x2_f32); PREC 1: split-f16, 3 x v_mfma_f32_32x32x16_f16
 // NS: LDS pipeline stages (power of two or 3); the DMA of tile k+NS-1 is issued while tile k is
 // multiplied, so NS-2 tiles stay in flight across a barrier (counted vmcnt + raw s_barrier)
@@ -238,22 +332,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             if (r < nk) producer_sync<r * (AR + BR)>();
         });
         __syncthreads();
-        if (p.stats == nullptr) return;
-        // fused GroupNorm statistics: the consumers leave per-(wave row, lane half, column) sums in
-        // LDS; the producer threads add them and write this tile's per-channel partials
-        __syncthreads();
-        {
-            const double2 *red = reinterpret_cast<const double2 *>(smem);
-            const int col = threadIdx.x - 256;
-            if (col < BN && n0 + col < Cout) {
-                double a = 0, b = 0;
-#pragma unroll
-                for (int j = 0; j < WGM * 2; ++j) { const double2 v = red[j * BN + col]; a += v.x; b += v.y; }
-                const int n = m0 / HWo, slice = (m0 - n * HWo) / BM;
-                double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0 + col) * 2;
-                o[0] = a; o[1] = b;
-            }
-        }
+        if (p.stats != nullptr) producer_stats_tail<BM, BN, WGM>(p, smem, m0, n0, HWo);
         return;
     }
 
@@ -366,65 +445,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= p.w_unscale;
     }
 
-    if (nsplit > 1) {
-        // split-K: raw partial sums to part[split][m][n]; the reduce kernel finishes the epilogue
-        float *pp = p.part + (size_t)split * M * Cout;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wn * WN + ni * 32 + li;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < M && n < Cout) pp[(size_t)m * Cout + n] = acc[mi][ni][r];
-                }
-        }
-        return;
-    }
-    // ---- epilogue: bias + FeatureWiseAffine channel bias + residual, stores into the padded
-    // output. C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Processed 4 accumulator registers (4 consecutive rows) at a time to keep registers low.
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + wn * WN + ni * 32 + li;
-        const int nc = min(n, Cout - 1);
-        const float bs = p.bias ? p.bias[nc] : 0.f;
-        double st1 = 0.0, st2 = 0.0;       // fused GroupNorm statistics of this lane's column
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int rbase = wm * WM + mi * 32 + 8 * rq + 4 * lh;
-                float add[4];
-                unsigned o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    add[j] = bs;
-                    o[j] = (unsigned)rowpix[rbase + j] * (unsigned)Cout + (unsigned)nc;
-                }
-                if (p.resid.p != nullptr) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) add[j] += p.resid.p[o[j]];
-                }
-                if (p.chan_bias != nullptr) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        add[j] += p.chan_bias[(size_t)rowimg[rbase + j] * p.chan_bias_stride + nc];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + rbase + j;
-                    const float v = acc[mi][ni][4 * rq + j] + add[j];
-                    if (m < M && n < Cout) p.out.p[o[j]] = v;
-                    if (p.stats != nullptr) { st1 += (double)v; st2 = fma((double)v, (double)v, st2); }
-                }
-            }
-        }
-        if (p.stats != nullptr)
-            reinterpret_cast<double2 *>(smem)[(wm * 2 + lh) * BN + wn * WN + ni * 32 + li] = make_double2(st1, st2);
-    }
-    if (p.stats != nullptr) __syncthreads();
+    conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, split, nsplit);
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int NS>
