@@ -448,6 +448,281 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
     conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, split, nsplit);
 }
 
+// =================================================================================================
+// x-halo variant (split-f16, 3x3, stride 1, no upsample): the three dx taps of one (chunk, dy) read
+// the same pixels shifted by one, so the A operand is staged ONCE per (chunk, dy) as row segments
+// with a 1-pixel halo on each side and the consumers address it at row offset dx. A-side LDS-DMA
+// instructions drop from 9 to ~3.1 per chunk (the DMA issue cost is what limits split-f16 mode).
+//   tile = BM consecutive output pixels = nseg segments of SEG = min(W, BM) pixels of one image row;
+//   A stage = nseg x (SEG + 2) rows of 128 B, row R of segment s = padded pixel (n, y + dy, x0 + R);
+//   consumer row for tile row r and tap dx: r + 2 * (r / SEG) + dx.
+// A ring: 2 stages, group g = (chunk, dy) lives in stage g & 1 and is issued two K-steps ahead (at
+// the dx = 1 step of the previous group); B ring: 2 stages, one tile per K-step as before.
+// The fused 1x1 term (in2) uses plain BM-row A tiles in the same A ring.
+// =================================================================================================
+template <int BM, int BN, int WGM, int WGN, int SEGMIN>
+__global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
+    static_assert(WGM * WGN == 4, "4 consumer waves per block");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int RA = BM + 2 * (BM / SEGMIN);          // rows of one A stage (worst case)
+    constexpr int ARH = (RA / 8 + 3) / 4;               // halo DMA instructions per producer wave
+    constexpr int ASTG = RA * ROWF, BSTG = BN * ROWF;
+    static_assert((RA % 8) == 0, "A stage rows");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Aring = smem;                    // [2][RA][32]
+    float *Bring = smem + 2 * ASTG;         // [2][BN][32]
+    int *rowpix = reinterpret_cast<int *>(smem + 2 * ASTG + 2 * BSTG);
+    int *rowimg = rowpix + BM;
+
+    const int C0 = p.in0.C, C1 = p.in1.p ? p.in1.C : 0;
+    const int Cin = C0 + C1;
+    const int Cout = p.out.C;
+    const int W = p.Wout;
+    const int HWo = p.Hout * W;
+    const int M = p.B * HWo;
+    const int tilesN = (Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, loc = bid >> 3;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+    }
+    const int m0 = (bid / tilesN) * BM;
+    const int n0 = (bid % tilesN) * BN;
+    const int SEG = min(W, BM), SEGP = SEG + 2, nseg = BM / SEG;
+    const int rows_a = nseg * SEGP;
+    const int nkh = 9 * (Cin / BK);                    // halo-phase K-steps
+    const int C2 = p.in2.p ? p.in2.C : 0;
+    const int nk = nkh + C2 / BK;
+    const int G = nkh / 3;                              // A groups of the halo phase
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    if (wid >= 4) {
+        // ------------------------------- producer waves -------------------------------------
+        const int w = wid - 4;
+        const int tid = threadIdx.x - 256;
+        if (tid < BM) {
+            const int m = min(m0 + tid, M - 1);
+            const int n = m / HWo;
+            const int rem = m - n * HWo;
+            const int oy = rem / W;
+            rowpix[tid] = (int)p.out.pix(n, oy, rem - oy * W);
+            rowimg[tid] = n;
+        }
+        const int rsub = lane >> 3;
+        const unsigned schunk16 = (unsigned)(((lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7)) * 16);
+        const int Hp = p.in0.Hp(), Wp = p.in0.Wp();
+        // halo rows: DMA instruction i of this wave fills A-stage rows (4i + w) * 8 + rsub
+        unsigned vH0[ARH], vH1[ARH];
+        static_for<ARH>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int R = (4 * i + w) * 8 + rsub;
+            int sg = R / SEGP, jx = R - sg * SEGP;
+            if (sg >= nseg) { sg = nseg - 1; jx = 0; }              // unused tail rows: any valid pixel
+            const int m = m0 + sg * SEG;
+            const int n = m / HWo;
+            const int rem = m - n * HWo;
+            const int y = rem / W, x0 = rem - y * W;
+            // padded coordinates of (y - 1 + dy, x0 - 1 + jx) are (y + dy, x0 + jx); dy is added per group
+            const unsigned pix = (unsigned)((n * Hp + y) * Wp + x0 + jx);
+            vH0[i] = pix * (unsigned)C0 * 4u + schunk16;
+            vH1[i] = pix * (unsigned)C1 * 4u + schunk16;
+        });
+        unsigned vB[BR], vB2[BR], vA2[AR];
+        static_for<BR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
+            vB[i] = (unsigned)n * (unsigned)Cin * 4u + schunk16;
+            vB2[i] = (unsigned)n * (unsigned)C2 * 4u + schunk16;
+        });
+        static_for<AR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
+            const int n = m / HWo;
+            const int rem = m - n * HWo;
+            const int oy = rem / W;
+            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * W) * (unsigned)C2 * 4u + schunk16 : 0u;
+        });
+        const size_t tapstride = (size_t)Cout * Cin;
+
+        // issue the halo tile of group (c0, dy) into A stage (ga & 1)
+        int ga = 0;
+#define SR3_ISSUE_HALO(C0A, DY)                                                                    \
+    {                                                                                              \
+        const int c0a_ = (C0A);                                                                    \
+        const bool first_ = c0a_ < C0;                                                             \
+        const int Cs_ = first_ ? C0 : C1;                                                          \
+        const char *ab_ = reinterpret_cast<const char *>((first_ ? p.in0.p : p.in1.p) + (first_ ? c0a_ : c0a_ - C0)) + \
+                          (size_t)(DY) * Wp * Cs_ * 4;                                             \
+        float *Ad_ = Aring + (ga & 1) * ASTG + w * 256;                                            \
+        static_for<ARH>([&](auto ic) {                                                             \
+            constexpr int i = decltype(ic)::value;                                                 \
+            if ((4 * i + w) * 8 < rows_a)                                                          \
+                dma16(reinterpret_cast<const float *>(ab_ + (first_ ? vH0[i] : vH1[i])), Ad_ + i * 1024); \
+        });                                                                                        \
+        ++ga;                                                                                      \
+    }
+
+        int k = 0;
+        SR3_ISSUE_HALO(0, 0)
+        for (int c0 = 0; c0 < Cin; c0 += BK) {
+            const char *wbase = reinterpret_cast<const char *>(p.w + c0);
+            static_for<9>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                constexpr int dy = tap / 3, dx = tap % 3;
+                if (dx == 1) {          // two K-steps before group (c0, dy + 1) / (c0 + BK, 0) starts
+                    if (dy < 2) {
+                        SR3_ISSUE_HALO(c0, dy + 1)
+                    } else if (c0 + BK < Cin) {
+                        SR3_ISSUE_HALO(c0 + BK, 0)
+                    }
+                }
+                float *Bd = Bring + (k & 1) * BSTG + w * 256;
+                const char *wb = wbase + (size_t)tap * tapstride * 4;
+                static_for<BR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                });
+                producer_sync<0>();
+                ++k;
+            });
+        }
+#undef SR3_ISSUE_HALO
+        // fused 1x1 term: plain BM-row A tiles continue in the A ring
+        for (int c0 = 0; c0 < C2; c0 += BK) {
+            float *Ad = Aring + (ga & 1) * ASTG + w * 256;
+            float *Bd = Bring + (k & 1) * BSTG + w * 256;
+            const char *ab = reinterpret_cast<const char *>(p.in2.p + c0);
+            const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
+            static_for<AR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                dma16(reinterpret_cast<const float *>(ab + vA2[i]), Ad + i * 1024);
+            });
+            static_for<BR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
+            });
+            producer_sync<0>();
+            ++k;
+            ++ga;
+        }
+        __syncthreads();
+        if (p.stats != nullptr) producer_stats_tail<BM, BN, WGM>(p, smem, m0, n0, HWo);
+        return;
+    }
+
+    // ----------------------------------- consumer waves -----------------------------------------
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wid / WGN, wn = wid % WGN;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // B rows are plain: the swizzle term is a per-lane constant
+    const int swzB = (li >> 1) & 7;
+    const float *Bbase = Bring + (wn * WN + li) * ROWF;
+    int hoffB[2], loffB[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+        hoffB[sb] = (((2 * sb + lh) ^ swzB) & 7) * 4;
+        loffB[sb] = (((4 + 2 * sb + lh) ^ swzB) & 7) * 4;
+    }
+    // A rows: halo row of tile row r for dx = 0 is r + 2 * (r / SEG); plain row (in2 phase) is r.
+    // (Precomputing per-(mi, dx) offsets and unrolling the three taps was measured slower: more
+    // registers, lower occupancy for the 128x64 tile.)
+    int rhalo[MI], rplain[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        rplain[mi] = wm * WM + mi * 32 + li;
+        rhalo[mi] = rplain[mi] + 2 * (rplain[mi] / SEG);
+    }
+    h16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+    // fragment reads of K-step KT, 16-wide K block SB into register set SET
+#define SR3_HREAD(SET, KT, SB)                                                                     \
+    {                                                                                              \
+        const int kt_ = (KT);                                                                      \
+        const bool halo_ = kt_ < nkh;                                                              \
+        const int g_ = kt_ / 3;                                                                    \
+        const int astage_ = halo_ ? (g_ & 1) : ((G + kt_ - nkh) & 1);                              \
+        const int dx_ = kt_ - 3 * g_;                                                              \
+        const float *Ab_ = Aring + astage_ * ASTG;                                                 \
+        const float *Bb_ = Bbase + (kt_ & 1) * BSTG;                                               \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
+            const int R_ = halo_ ? rhalo[mi] + dx_ : rplain[mi];                                   \
+            const int sw_ = (R_ >> 1) & 7;                                                         \
+            ah[SET][mi] = *reinterpret_cast<const h16x8 *>(Ab_ + R_ * ROWF + (((2 * (SB) + lh) ^ sw_) & 7) * 4);     \
+            al[SET][mi] = *reinterpret_cast<const h16x8 *>(Ab_ + R_ * ROWF + (((4 + 2 * (SB) + lh) ^ sw_) & 7) * 4); \
+        }                                                                                          \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
+            bh[SET][ni] = *reinterpret_cast<const h16x8 *>(Bb_ + ni * 32 * ROWF + hoffB[SB]);      \
+            bl[SET][ni] = *reinterpret_cast<const h16x8 *>(Bb_ + ni * 32 * ROWF + loffB[SB]);      \
+        }                                                                                          \
+    }
+#define SR3_HMMA(SET)                                                                              \
+    {                                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bl[SET][ni], acc[mi][ni], 0, 0, 0); \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+        }                                                                                          \
+    }
+    __syncthreads();
+    SR3_HREAD(0, 0, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        SR3_HREAD(1, kt, 1)
+        SR3_HMMA(0)
+        __syncthreads();                       // every read of tile kt has been issued and waited
+        SR3_HREAD(0, min(kt + 1, nk - 1), 0)   // next tile (re-reads the last one at the end: unused)
+        SR3_HMMA(1)
+    }
+#undef SR3_HREAD
+#undef SR3_HMMA
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= p.w_unscale;
+    conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, 0, 1);
+}
+
+template <int BM, int BN, int WGM, int WGN, int SEGMIN>
+void launch_halo(const ConvParams &p, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr int RA = BM + 2 * (BM / SEGMIN);
+    constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM) * sizeof(float);
+    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int M = p.B * p.Hout * p.Wout;
+    hipLaunchKernelGGL(kern, dim3((M / BM) * ((p.out.C + BN - 1) / BN)), dim3(512), lds, s, p);
+}
+
+// preconditions of the x-halo kernel for tile height BM
+static bool halo_ok(const ConvParams &p, int BM, int segmin) {
+    static const int off = getenv("SR3_NO_HALO") ? atoi(getenv("SR3_NO_HALO")) : 0;
+    if (off || p.prec != 1 || p.ks != 3 || p.stride != 1 || p.up2 || p.splits > 1 || p.in0.pad != 1) return false;
+    const int W = p.Wout;
+    if (p.in0.W != W || p.in0.H != p.Hout) return false;
+    const int seg = W < BM ? W : BM;
+    if (seg < segmin || (W % seg) || (BM % seg)) return false;
+    const long M = (long)p.B * p.Hout * W;
+    return (M % BM) == 0 && (!p.in2.p || (p.in2.C % 32) == 0);
+}
+
 template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int NS>
 void launch_inst2(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
@@ -548,9 +823,15 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     if (p.splits > 1) p.stats = nullptr;   // the caller falls back to the statistics kernel
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
-    case 1: launch_cfg<128, 64, 2, 2>(p, s); break;
+    case 1:
+        if (halo_ok(p, 128, 32)) launch_halo<128, 64, 2, 2, 32>(p, s);
+        else launch_cfg<128, 64, 2, 2>(p, s);
+        break;
     case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
-    default: launch_cfg<128, 128, 2, 2>(p, s); break;
+    default:
+        if (halo_ok(p, 128, 8)) launch_halo<128, 128, 2, 2, 8>(p, s);
+        else launch_cfg<128, 128, 2, 2>(p, s);
+        break;
     }
     if (p.splits > 1) {
         const size_t items = (size_t)M * (p.out.C >> 2);
