@@ -75,6 +75,8 @@ PROTOTYPES = {
     "sr3_op_nchw_to_nhwc": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "sr3_op_nhwc_to_nchw": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "sr3_preprocess_bicubic": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "sr3_postprocess_u8": (_I, [_P, _F, _I, _I, _I, _I, _I, _P, _P, _F, _F]),
+    "sr3_postprocess_tensor_blob": (_I, [_P, _F, _I, _I, _I, _I, _F]),
     "sr3_dev_malloc": (_I, [_P, _U64, C.POINTER(_P)]),
     "sr3_dev_free": (_I, [_P, _P]),
     "sr3_memcpy_h2d": (_I, [_P, _P, _P, _U64]),

@@ -897,6 +897,7 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
         }
         p.loaded = true;
         c->fused_dirty = true;
+        drop_graphs(c);     // captured steps hold the old w_unscale scalars in their kernel arguments
         return 0;
     }
     return fail("unknown parameter '%s'", name);
@@ -1259,6 +1260,75 @@ int sr3_preprocess_bicubic(sr3_ctx *c, const uint8_t *in_hwc_dev, int B, int Hin
                       out_u8_hwc_dev, c->stream);
     HIP_OK(hipStreamSynchronize(c->stream));   // the coefficient vectors and buf go out of scope
     HIP_OK(hipFree(buf));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- post-processing ---------------------------------------------------------------------------
+int sr3_postprocess_u8(sr3_ctx *c, const float *sr, int B, int H, int W, int up, int blob, uint8_t *img_u8,
+                       uint8_t *up_u8, float *images, float *arcface) {
+    if (!c || !sr) return fail("sr3_postprocess_u8: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || up < 0 || blob < 0) return fail("sr3_postprocess_u8: bad size");
+    if (!up && (up_u8 || images)) return fail("sr3_postprocess_u8: up_u8 / images need up > 0");
+    if (arcface && blob <= 0) return fail("sr3_postprocess_u8: arcface needs blob > 0");
+    if (!up && H != W) return fail("sr3_postprocess_u8: up == 0 needs square images");
+    HIP_OK(hipSetDevice(c->device));
+    const int S = up ? up : H;                    // side of the image the blob is made from
+    const bool want_up = up && (up_u8 || images || arcface);
+    // blobFromImages resizes with INTER_LINEAR unless the size already matches; an exact factor
+    // of 2 takes cv2's area shortcut
+    const int f = !arcface ? 0 : (S == blob ? 1 : (S == 2 * blob ? 2 : 0));
+    const bool blob_resize = arcface && f == 0;
+    std::vector<int> tab, o, ab;
+    size_t tab_up = 0, tab_blob = 0;
+    auto add_tab = [&](int in_h, int in_w, int out_h, int out_w) {
+        const size_t at = tab.size();
+        cv_linear_coeffs(in_w, out_w, true, o, ab);
+        tab.insert(tab.end(), o.begin(), o.end());
+        tab.insert(tab.end(), ab.begin(), ab.end());
+        cv_linear_coeffs(in_h, out_h, false, o, ab);
+        tab.insert(tab.end(), o.begin(), o.end());
+        tab.insert(tab.end(), ab.begin(), ab.end());
+        return at;
+    };
+    if (want_up) tab_up = add_tab(H, W, up, up);
+    if (blob_resize) tab_blob = add_tab(S, S, blob, blob);
+    const size_t n_img = (size_t)B * H * W * 3, n_up = want_up ? (size_t)B * up * up * 3 : 0;
+    const size_t n_bl = blob_resize ? (size_t)B * blob * blob * 3 : 0;
+    char *buf = nullptr;
+    HIP_OK(hipMalloc(&buf, tab.size() * 4 + n_img + n_up + n_bl + 64));
+    int *d_tab = reinterpret_cast<int *>(buf);
+    uint8_t *t_img = reinterpret_cast<uint8_t *>(d_tab + tab.size());
+    uint8_t *t_up = t_img + n_img, *t_bl = t_up + n_up;
+    if (!tab.empty()) HIP_OK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    uint8_t *img = img_u8 ? img_u8 : t_img;
+    launch_tensor2img(sr, B, H, W, img, c->stream);
+    const uint8_t *src = img;
+    if (want_up) {
+        uint8_t *u = up_u8 ? up_u8 : t_up;
+        launch_resize_linear_u8(img, B, H, W, up, up, d_tab + tab_up, u, images, c->stream);
+        src = u;
+    }
+    if (arcface) {
+        const float mean = 127.5f, scale = (float)(1.0 / 127.5);
+        if (blob_resize) {
+            launch_resize_linear_u8(src, B, S, S, blob, blob, d_tab + tab_blob, t_bl, nullptr, c->stream);
+            launch_blob(t_bl, B, blob, blob, 1, mean, scale, arcface, c->stream);
+        } else {
+            launch_blob(src, B, blob, blob, f, mean, scale, arcface, c->stream);
+        }
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));   // temporaries and host tables go out of scope
+    HIP_OK(hipFree(buf));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sr3_postprocess_tensor_blob(sr3_ctx *c, const float *sr, int B, int H, int W, int blob, float *arcface) {
+    if (!c || !sr || !arcface) return fail("sr3_postprocess_tensor_blob: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || blob <= 0) return fail("sr3_postprocess_tensor_blob: bad size");
+    HIP_OK(hipSetDevice(c->device));
+    launch_tensor_blob(sr, B, H, W, blob, blob, arcface, c->stream);
     HIP_OK(hipGetLastError());
     return 0;
 }

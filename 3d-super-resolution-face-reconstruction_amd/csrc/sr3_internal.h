@@ -146,4 +146,14 @@ void launch_resample_h(const uint8_t *in, int B, int H, int Win, int Wout, const
 void launch_resample_v(const uint8_t *in, int B, int Hin, int Hout, int W, const int *bounds, const int *kk,
                        int ksize, float *out_nchw, uint8_t *out_u8, hipStream_t s);
 
+// ---- post-processing: tensor2img / cv2-style 8-bit linear resize / ArcFace blob (kernels_post.hip) ----
+void cv_linear_coeffs(int in_size, int out_size, bool horizontal, std::vector<int> &ofs, std::vector<int> &ab);
+void launch_tensor2img(const float *in_nchw, int B, int H, int W, uint8_t *out_hwc, hipStream_t s);
+// tab = xofs[Wd] | xa[Wd][2] | yofs[Hd] | yb[Hd][2]; images (optional) = dst / 255 as [B][3][Hd][Wd]
+void launch_resize_linear_u8(const uint8_t *src, int B, int Hs, int Ws, int Hd, int Wd, const int *tab, uint8_t *dst,
+                             float *images, hipStream_t s);
+// src is f x the blob size (f = 1 | 2); out [B][3][Hb][Wb], channels swapped, (avg - mean) * scale
+void launch_blob(const uint8_t *src, int B, int Hb, int Wb, int f, float mean, float scale, float *out, hipStream_t s);
+void launch_tensor_blob(const float *in_nchw, int B, int H, int W, int Hb, int Wb, float *out, hipStream_t s);
+
 } // namespace sr3

@@ -57,9 +57,17 @@ class GaussianDiffusion(nn.Module):
         eng = self.denoise_fn.engine()
         if self._sched_np is None:
             raise Sr3Error("set_new_noise_schedule() has not been called")
-        if self._sched_pushed != id(eng):
-            eng.set_schedule(self._sched_np)
-            self._sched_pushed = id(eng)
+        # like the reference, sample with whatever the registered buffers hold now (a checkpoint's
+        # load_state_dict may have replaced them, diffusion.py:144-162 reads self.<buffer>[t]); the
+        # noise levels come from the config-derived float64 array (diffusion.py:108-109,166-167)
+        sig = (id(eng),) + tuple((self._buffers[k].data_ptr(), self._buffers[k]._version)
+                                 for k in _schedule.ENGINE_BUFFERS)
+        if self._sched_pushed != sig:
+            bufs = {"noise_level": self._sched_np["noise_level"]}
+            for k in _schedule.ENGINE_BUFFERS:
+                bufs[k] = self._buffers[k].detach().to("cpu", torch.float32).numpy()
+            eng.set_schedule(bufs)
+            self._sched_pushed = sig
         return eng
 
     # ---- sampling ------------------------------------------------------------------------------

@@ -200,6 +200,46 @@ class Engine:
         return dout.download((B, 3, Hout, Wout)), u8.reshape(B, Hout, Wout, 3)
 
     # ---- measurement ------------------------------------------------------------------------
+    # ---- post-processing ------------------------------------------------
+    def postprocess_u8(self, sr_ptr: int, B: int, H: int, W: int, up: int = 224, blob: int = 112,
+                       img_u8_ptr: Optional[int] = None, up_u8_ptr: Optional[int] = None,
+                       images_ptr: Optional[int] = None, arcface_ptr: Optional[int] = None) -> None:
+        _lib.check(self.lib.sr3_postprocess_u8(self.ctx, sr_ptr, B, H, W, up, blob, img_u8_ptr, up_u8_ptr,
+                                               images_ptr, arcface_ptr))
+
+    def postprocess_tensor_blob(self, sr_ptr: int, B: int, H: int, W: int, blob: int, arcface_ptr: int) -> None:
+        _lib.check(self.lib.sr3_postprocess_tensor_blob(self.ctx, sr_ptr, B, H, W, blob, arcface_ptr))
+
+    def postprocess_np(self, sr: np.ndarray, up: int = 224, blob: int = 112) -> Dict[str, np.ndarray]:
+        """Host-array convenience (tests): fp32 [B,3,H,W] -> dict(img_u8, up_u8, images, arcface,
+        tensor_arcface)."""
+        sr = _host_f32(sr)
+        B, _, H, W = sr.shape
+        S = up if up else H
+        d_in = self.to_device(sr)
+        sizes = {"img_u8": B * H * W * 3, "up_u8": B * S * S * 3}
+        bufs = {k: self.buffer((n + 3) // 4) for k, n in sizes.items()}
+        bufs["images"] = self.buffer(B * 3 * S * S)
+        bufs["arcface"] = self.buffer(B * 3 * blob * blob)
+        bufs["tensor_arcface"] = self.buffer(B * 3 * blob * blob)
+        self.postprocess_u8(d_in.ptr, B, H, W, up, blob, bufs["img_u8"].ptr,
+                            bufs["up_u8"].ptr if up else None, bufs["images"].ptr if up else None,
+                            bufs["arcface"].ptr)
+        self.postprocess_tensor_blob(d_in.ptr, B, H, W, blob, bufs["tensor_arcface"].ptr)
+        out = {}
+        for k, shape in (("img_u8", (B, H, W, 3)), ("up_u8", (B, S, S, 3))):
+            if k == "up_u8" and not up:
+                continue
+            raw = bufs[k].download()
+            out[k] = raw.view(np.uint8)[: sizes[k]].reshape(shape).copy()
+        if up:
+            out["images"] = bufs["images"].download((B, 3, S, S))
+        out["arcface"] = bufs["arcface"].download((B, 3, blob, blob))
+        out["tensor_arcface"] = bufs["tensor_arcface"].download((B, 3, blob, blob))
+        for b in list(bufs.values()) + [d_in]:
+            b.free()
+        return out
+
     def profile_enable(self, on: bool):
         _lib.check(self.lib.sr3_profile_enable(self.ctx, 1 if on else 0))
 

@@ -17,6 +17,9 @@ BUFFER_NAMES = (
     "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
     "posterior_mean_coef1", "posterior_mean_coef2",
 )
+# the five per-step arrays the sampler reads (diffusion.py:144-162,182-187)
+ENGINE_BUFFERS = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2")
 
 
 def make_beta_schedule(schedule: str, n_timestep: int, linear_start: float = 1e-4,

@@ -182,6 +182,31 @@ int sr3_op_nhwc_to_nchw(sr3_ctx *ctx, const float *in_dev, int B, int C, int H, 
 int sr3_preprocess_bicubic(sr3_ctx *ctx, const uint8_t *in_hwc_dev, int B, int Hin, int Win, int Hout,
                            int Wout, float *out_nchw_dev, uint8_t *out_u8_hwc_dev);
 
+/* ---- post-processing behind the sampler ------------------------------------------------------ */
+
+/* replaces the host chain between the sampler and the MICA / ArcFace encoder
+ * (model/sr3d/model.py:372-386 and :462-471):
+ *   img_u8  = Metrics.tensor2img(SR)                     core/metrics.py:16-42  [B,H,W,3] RGB
+ *   up_u8   = cv2.resize(img_u8, (up, up))               model/sr3d/model.py:380 [B,up,up,3]
+ *   images  = up_u8.transpose(2,0,1) / 255               model/sr3d/model.py:383-385 [B,3,up,up] fp32
+ *   arcface = cv2.dnn.blobFromImages([up_u8], 1/127.5, (blob, blob), 127.5, swapRB=True)[0]
+ *                                                         model/sr3d/model.py:127-131 [B,3,blob,blob]
+ * sr_nchw: fp32 [B,3,H,W] in [-1,1] (the sampler's output). Every output pointer is optional
+ * (null = not wanted); all are device pointers. up == 0 skips the resize (arcface is then built
+ * from img_u8). cv2's 8-bit INTER_LINEAR (and its scale-2 INTER_AREA shortcut inside
+ * blobFromImages) is restated from OpenCV 4.x resize.cpp — parity unpinned, cv2 is not installed.
+ * Synchronous. */
+int sr3_postprocess_u8(sr3_ctx *ctx, const float *sr_nchw_dev, int B, int H, int W, int up, int blob,
+                       uint8_t *img_u8_dev, uint8_t *up_u8_dev, float *images_dev, float *arcface_dev);
+
+/* replaces the tensor chain of model3 (model/sr3d/model.py:474-483):
+ *   arcface = create_tensor_blob(tensor2tensor_img(SR) * 255)   model/sr3d/model.py:105-124,
+ *                                                                core/metrics.py:44-50
+ * i.e. clamp, [0,255] scaling, (x-127.5)/127.5, torch bilinear resize (align_corners=False) to
+ * blob x blob, RGB->BGR. out: fp32 [B,3,blob,blob]. Asynchronous on the context's stream. */
+int sr3_postprocess_tensor_blob(sr3_ctx *ctx, const float *sr_nchw_dev, int B, int H, int W, int blob,
+                                float *arcface_dev);
+
 /* ---- device memory helpers (so hosts without torch can drive the library) ---------------- */
 int sr3_dev_malloc(sr3_ctx *ctx, uint64_t bytes, void **out_dev);
 int sr3_dev_free(sr3_ctx *ctx, void *dev);

@@ -74,3 +74,30 @@ def test_pil_bicubic_restatement_bit_exact():
     np.testing.assert_array_equal(pb.resize_u8(lr, 128, 128), g["chain_sr"])
     t = pb.to_tensor_pm1(g["chain_sr"])
     assert t.shape == (3, 128, 128) and t.dtype == np.float32 and t.min() >= -1 and t.max() <= 1
+
+
+def test_post_oracle_self_consistency():
+    """oracle/post_oracle.py. No cv2 fixture exists (parity unpinned), so the
+    restated fixed-point resize is held to what it approximates: within 1 grey level of the exact
+    bilinear value, exact on constant images, and identity-like at scale 1; tensor2img is checked
+    on hand-computed values (round half to even, clamp)."""
+    import post_oracle as post
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (128, 128, 3)).astype(np.uint8)
+    for size in (224, 200, 131):
+        up = post.cv2_resize_linear_u8(img, size, size)
+        assert up.shape == (size, size, 3) and up.dtype == np.uint8
+        assert np.abs(up.astype(np.float64) - post.float_bilinear_u8(img, size, size)).max() <= 1.0
+    flat = np.full((16, 16, 3), 201, np.uint8)
+    assert (post.cv2_resize_linear_u8(flat, 224, 224) == 201).all()
+    x = np.zeros((3, 2, 2), np.float32)
+    x[0, 0, 0], x[0, 0, 1], x[0, 1, 0], x[0, 1, 1] = -3.0, 3.0, 1.0 / 255, 3.0 / 255   # 0, 255, 128 (127.5+.5 -> even 128), 129 (128.5+.5)
+    got = post.tensor2img(x)[:, :, 0]
+    assert got.tolist() == [[0, 255], [128, 129]]
+    blob = post.cv2_blob_from_image(post.cv2_resize_linear_u8(img, 224, 224), 112)
+    assert blob.shape == (3, 112, 112) and blob.dtype == np.float32
+    area = post.cv2_resize_linear_u8(img, 224, 224).astype(np.int64)
+    r00 = (area[0, 0, 0] + area[0, 1, 0] + area[1, 0, 0] + area[1, 1, 0] + 2) >> 2
+    assert blob[2, 0, 0] == np.float32((np.float32(r00) - np.float32(127.5)) * np.float32(1 / 127.5))   # swapRB: R is channel 2
+    tb = post.tensor_blob_torch(rs.uniform(-1, 1, (1, 3, 128, 128)).astype(np.float32))
+    assert tb.shape == (1, 3, 112, 112) and np.abs(tb).max() <= 1.0 + 1e-6
