@@ -73,7 +73,7 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// KS: 1 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into the gather
+// KS: 1 | 2 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into a 9-tap gather (A/B only)
 // Consumer epilogue shared by the conv kernels: split-K partials, or accumulator + bias +
 // FeatureWiseAffine channel bias + residual into the zero-bordered output, plus the fused
 // GroupNorm statistics (per-column fp64 sums left in LDS for the producer threads).
@@ -162,7 +162,7 @@ __device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const f
         double a = 0, b = 0;
 #pragma unroll
         for (int j = 0; j < WGM * 2; ++j) { const double2 v = red[j * BN + col]; a += v.x; b += v.y; }
-        const int n = m0 / HWo, slice = (m0 - n * HWo) / BM;
+        const int n = m0 / HWo, slice = p.stats_slice0 + (m0 - n * HWo) / BM;
         double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0 + col) * 2;
         o[0] = a; o[1] = b;
     }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             const int n = m / HWo;
             const int rem = m - n * HWo;
             const int oy = rem / p.Wout;
-            rowpix[tid] = (int)p.out.pix(n, oy, rem - oy * p.Wout);
+            rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox);
             rowimg[tid] = n;
         }
         // DMA instruction i of this wave fills tile rows (4i + w) * 8 + (lane >> 3), lane & 7 is
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                     vX[UP2 ? i : 0][d] = (unsigned)sx * (unsigned)C0 * 4u + schunk16;
                 }
             } else {
-                const unsigned pixbase = (unsigned)((n * Hp + oy * p.stride - cpad + tpad) * Wp +
-                                                    ox * p.stride - cpad + tpad);
+                const unsigned pixbase = (unsigned)((n * Hp + oy * p.stride - cpad + tpad + p.org_y) * Wp +
+                                                    ox * p.stride - cpad + tpad + p.org_x);
                 vA0[i] = pixbase * (unsigned)C0 * 4u + schunk16;
                 vA1[i] = pixbase * (unsigned)C1 * 4u + schunk16;
             }
@@ -460,13 +460,14 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // the dx = 1 step of the previous group); B ring: 2 stages, one tile per K-step as before.
 // The fused 1x1 term (in2) uses plain BM-row A tiles in the same A ring.
 // =================================================================================================
-template <int BM, int BN, int WGM, int WGN, int SEGMIN>
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS>
 __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;
-    constexpr int RA = BM + 2 * (BM / SEGMIN);          // rows of one A stage (worst case)
+    constexpr int HALO = KS - 1, TAPS = KS * KS;         // KS 3: 3x3 conv; KS 2: one sub-pixel phase of the upsample conv
+    constexpr int RA = (BM + HALO * (BM / SEGMIN) + 7) / 8 * 8;   // rows of one A stage (worst case, whole DMA instructions)
     constexpr int ARH = (RA / 8 + 3) / 4;               // halo DMA instructions per producer wave
     constexpr int ASTG = RA * ROWF, BSTG = BN * ROWF;
     static_assert((RA % 8) == 0, "A stage rows");
@@ -493,12 +494,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
     }
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
-    const int SEG = min(W, BM), SEGP = SEG + 2, nseg = BM / SEG;
+    const int SEG = min(W, BM), SEGP = SEG + HALO, nseg = BM / SEG;
     const int rows_a = nseg * SEGP;
-    const int nkh = 9 * (Cin / BK);                    // halo-phase K-steps
+    const int nkh = TAPS * (Cin / BK);                 // halo-phase K-steps
     const int C2 = p.in2.p ? p.in2.C : 0;
     const int nk = nkh + C2 / BK;
-    const int G = nkh / 3;                              // A groups of the halo phase
+    const int G = nkh / KS;                             // A groups of the halo phase
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
             const int n = m / HWo;
             const int rem = m - n * HWo;
             const int oy = rem / W;
-            rowpix[tid] = (int)p.out.pix(n, oy, rem - oy * W);
+            rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
             rowimg[tid] = n;
         }
         const int rsub = lane >> 3;
@@ -528,8 +529,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
             const int n = m / HWo;
             const int rem = m - n * HWo;
             const int y = rem / W, x0 = rem - y * W;
-            // padded coordinates of (y - 1 + dy, x0 - 1 + jx) are (y + dy, x0 + jx); dy is added per group
-            const unsigned pix = (unsigned)((n * Hp + y) * Wp + x0 + jx);
+            // KS 3: padded coordinates of (y - 1 + dy, x0 - 1 + jx) are (y + dy, x0 + jx); KS 2: the phase's
+            // window starts at padded (y + org_y, x0 + org_x); dy is added per group
+            const unsigned pix = (unsigned)((n * Hp + y + p.org_y) * Wp + x0 + jx + p.org_x);
             vH0[i] = pix * (unsigned)C0 * 4u + schunk16;
             vH1[i] = pix * (unsigned)C1 * 4u + schunk16;
         });
@@ -572,11 +574,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
         SR3_ISSUE_HALO(0, 0)
         for (int c0 = 0; c0 < Cin; c0 += BK) {
             const char *wbase = reinterpret_cast<const char *>(p.w + c0);
-            static_for<9>([&](auto tc) {
+            static_for<TAPS>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
-                constexpr int dy = tap / 3, dx = tap % 3;
-                if (dx == 1) {          // two K-steps before group (c0, dy + 1) / (c0 + BK, 0) starts
-                    if (dy < 2) {
+                constexpr int dy = tap / KS, dx = tap % KS;
+                if (dx == 1) {          // the stage of group g-1 is free once K-step KS*g - 1 has been read
+                    if (dy < KS - 1) {
                         SR3_ISSUE_HALO(c0, dy + 1)
                     } else if (c0 + BK < Cin) {
                         SR3_ISSUE_HALO(c0 + BK, 0)
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         rplain[mi] = wm * WM + mi * 32 + li;
-        rhalo[mi] = rplain[mi] + 2 * (rplain[mi] / SEG);
+        rhalo[mi] = rplain[mi] + HALO * (rplain[mi] / SEG);
     }
     h16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
     // fragment reads of K-step KT, 16-wide K block SB into register set SET
@@ -651,9 +653,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
     {                                                                                              \
         const int kt_ = (KT);                                                                      \
         const bool halo_ = kt_ < nkh;                                                              \
-        const int g_ = kt_ / 3;                                                                    \
+        const int g_ = kt_ / KS;                                                                   \
         const int astage_ = halo_ ? (g_ & 1) : ((G + kt_ - nkh) & 1);                              \
-        const int dx_ = kt_ - 3 * g_;                                                              \
+        const int dx_ = kt_ - KS * g_;                                                             \
         const float *Ab_ = Aring + astage_ * ASTG;                                                 \
         const float *Bb_ = Bbase + (kt_ & 1) * BSTG;                                               \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
@@ -696,12 +698,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
     conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, 0, 1);
 }
 
-template <int BM, int BN, int WGM, int WGN, int SEGMIN>
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS>
 void launch_halo(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
-    constexpr int RA = BM + 2 * (BM / SEGMIN);
+    constexpr int RA = (BM + (KS - 1) * (BM / SEGMIN) + 7) / 8 * 8;
     constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM) * sizeof(float);
-    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN>;
+    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -714,7 +716,7 @@ void launch_halo(const ConvParams &p, hipStream_t s) {
 // preconditions of the x-halo kernel for tile height BM
 static bool halo_ok(const ConvParams &p, int BM, int segmin) {
     static const int off = getenv("SR3_NO_HALO") ? atoi(getenv("SR3_NO_HALO")) : 0;
-    if (off || p.prec != 1 || p.ks != 3 || p.stride != 1 || p.up2 || p.splits > 1 || p.in0.pad != 1) return false;
+    if (off || p.prec != 1 || (p.ks != 3 && p.ks != 2) || p.stride != 1 || p.up2 || p.splits > 1 || p.in0.pad != 1) return false;
     const int W = p.Wout;
     if (p.in0.W != W || p.in0.H != p.Hout) return false;
     const int seg = W < BM ? W : BM;
@@ -751,10 +753,12 @@ template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(const ConvParams &p, hipStream_t s) {
     if (p.prec == 0) {
         if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0, 0>(p, s);
+        else if (p.ks == 2) launch_inst<BM, BN, WGM, WGN, 2, 0, 0>(p, s);
         else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1, 0>(p, s);
         else launch_inst<BM, BN, WGM, WGN, 3, 0, 0>(p, s);
     } else {
         if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0, 1>(p, s);
+        else if (p.ks == 2) launch_inst<BM, BN, WGM, WGN, 2, 0, 1>(p, s);
         else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1, 1>(p, s);
         else launch_inst<BM, BN, WGM, WGN, 3, 0, 1>(p, s);
     }
@@ -777,7 +781,7 @@ __global__ void conv_splitk_reduce_kernel(const ConvParams p, int M, int HWo) {
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     const int img = m / HWo, rem = m - img * HWo, oy = rem / p.Wout;
-    const size_t o = p.out.pix(img, oy, rem - oy * p.Wout) * Cout + n;
+    const size_t o = p.out.pix(img, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox) * Cout + n;
     float v[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -824,12 +828,12 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
-        if (halo_ok(p, 128, 32)) launch_halo<128, 64, 2, 2, 32>(p, s);
+        if (halo_ok(p, 128, 32)) { if (p.ks == 3) launch_halo<128, 64, 2, 2, 32, 3>(p, s); else launch_halo<128, 64, 2, 2, 32, 2>(p, s); }
         else launch_cfg<128, 64, 2, 2>(p, s);
         break;
     case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
     default:
-        if (halo_ok(p, 128, 8)) launch_halo<128, 128, 2, 2, 8>(p, s);
+        if (halo_ok(p, 128, 8)) { if (p.ks == 3) launch_halo<128, 128, 2, 2, 8, 3>(p, s); else launch_halo<128, 128, 2, 2, 8, 2>(p, s); }
         else launch_cfg<128, 128, 2, 2>(p, s);
         break;
     }
@@ -838,6 +842,49 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p,
                            (int)M, p.Hout * p.Wout);
     }
+}
+
+void launch_conv_up2(const ConvParams &p_in, hipStream_t s) {
+    static const int gather = getenv("SR3_UP2_GATHER") ? atoi(getenv("SR3_UP2_GATHER")) : 0;   // A/B: old 9-tap gather
+    if (gather) { launch_conv(p_in, s); return; }
+    const int H = p_in.Hout / 2, W = p_in.Wout / 2, Cout = p_in.out.C;
+    const int Cin = p_in.in0.C + (p_in.in1.p ? p_in.in1.C : 0);
+    const long Ml = (long)p_in.B * H * W;
+    const int per_phase = (H * W) / conv_tile_m(Ml, Cout);
+    for (int ph = 0; ph < 4; ++ph) {
+        ConvParams p = p_in;
+        p.ks = 2; p.stride = 1; p.up2 = 0;
+        p.Hout = H; p.Wout = W;
+        p.org_y = p.out_oy = ph >> 1;
+        p.org_x = p.out_ox = ph & 1;
+        p.out_step = 2;
+        p.w = p_in.w + (size_t)ph * 4 * Cout * Cin;
+        p.stats_slice0 = ph * per_phase;
+        p.splits = p.part ? conv_splits(Ml, Cout, Cin) : 1;
+        launch_conv(p, s);
+    }
+}
+
+void make_up2_phase_weights(const float *w9, int Cout, int CinPad, float *dst) {
+    // nearest x2 then 3x3: output row 2y+py reads upsampled rows 2y+py-1..2y+py+1, i.e. source
+    // rows (2y+py+d-1)>>1 for d = 0..2: py = 0 -> {y-1, y, y}, py = 1 -> {y, y, y+1}. Window row
+    // r2 (0|1) of the phase is source row y-1+py+r2; the same holds for columns.
+    const size_t plane = (size_t)Cout * CinPad;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int r2 = 0; r2 < 2; ++r2)
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    float *d = dst + ((size_t)(py * 2 + px) * 4 + r2 * 2 + c2) * plane;
+                    for (size_t i = 0; i < plane; ++i) {
+                        double acc = 0.0;
+                        for (int dy = 0; dy < 3; ++dy) {
+                            if (((py + dy + 1) >> 1) != py + r2) continue;     // source row offset (+1) of tap dy
+                            for (int dx = 0; dx < 3; ++dx)
+                                if (((px + dx + 1) >> 1) == px + c2) acc += (double)w9[(size_t)(dy * 3 + dx) * plane + i];
+                        }
+                        d[i] = (float)acc;
+                    }
+                }
 }
 
 void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, float *dst) {

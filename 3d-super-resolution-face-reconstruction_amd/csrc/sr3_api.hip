@@ -51,6 +51,7 @@ struct Param {
     float *dev_split = nullptr;                  // P_CONV: split-f16 copy (prec 1), same size
     float w_unscale = 1.0f;
     bool keep_host = false;                      // part of a fused (conv2 + res_conv) launch
+    bool up_phase = false;                       // Upsample conv: stored as 4 sub-pixel phases x 2x2 taps
     std::vector<float> host;                     // packed fp32 weights / bias kept for re-scaling
     size_t dev_floats = 0;
     bool owns = true;                            // false: a view into a concatenated buffer
@@ -314,6 +315,7 @@ int build_graph(sr3_ctx *c) {
             Module m;
             m.kind = M_UP;
             m.conv = add_conv(c, "ups." + std::to_string(idx++) + ".conv", pre, pre, 3, true);
+            c->params[m.conv.w].up_phase = true;
             c->mods.push_back(m);
             now_res *= 2;
         }
@@ -344,7 +346,7 @@ int alloc_weights(sr3_ctx *c) {
             continue;
         }
         size_t n = 1;
-        if (p.kind == P_CONV) n = (size_t)p.ks * p.ks * p.cout * p.cin_pad;
+        if (p.kind == P_CONV) n = (size_t)(p.up_phase ? 16 : p.ks * p.ks) * p.cout * p.cin_pad;
         else for (auto d : p.shape) n *= (size_t)d;
         p.dev_floats = n;
         HIP_OK(hipMalloc(&p.dev, n * sizeof(float)));
@@ -438,14 +440,20 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             if (m.kind == M_RES) {
                 want(oc, m.rb.cin); want(oc, oc);
                 if (m.rb.attn) { want(3 * oc, oc); want(oc, oc); }
+            } else if (m.kind == M_UP) {
+                const long Ml = Mo / 4;                       // each sub-pixel phase is a conv over the low-res pixels
+                const int sp = conv_splits(Ml, oc, m.conv.cin_pad);
+                if (sp > 1) max_part = std::max<uint64_t>(max_part, (uint64_t)sp * Ml * oc);
             } else {
                 want(oc, m.conv.cin_pad);
             }
         }
         {   // fused statistics: every conv writing an [oc, h, w] tensor uses the same tile height
-            const int bm = conv_tile_m((long)B * h * w, oc);
-            if ((h * w) % bm == 0) {
-                s_slices[i] = (h * w) / bm;
+            const bool up = m.kind == M_UP;                   // 4 phases, each tiled over the low-res image
+            const int hw = up ? (h * w) / 4 : h * w;
+            const int bm = conv_tile_m((long)B * hw, oc);
+            if (hw % bm == 0) {
+                s_slices[i] = (up ? 4 : 1) * (hw / bm);
                 const uint64_t sf = (uint64_t)B * s_slices[i] * oc * 4;   // 2 doubles per channel
                 so_off[i] = cv.take(sf);
                 sr_off[i] = cv.take(sf);
@@ -512,7 +520,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             if (m.kind == M_RES) {
                 if (conv_splits(Mo, m.oc, m.rb.cin) > 1) m.st_h1 = StatsRef();
                 if (conv_splits(Mo, m.oc, m.oc) > 1) { m.st_rb = StatsRef(); m.st_out = StatsRef(); }
-            } else if (conv_splits(Mo, m.oc, m.conv.cin_pad) > 1) {
+            } else if (conv_splits(m.kind == M_UP ? Mo / 4 : Mo, m.oc, m.conv.cin_pad) > 1) {
                 m.st_out = StatsRef();
             }
         }
@@ -576,7 +584,8 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
         p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;
     }
     c->pbegin(F_CONV);
-    launch_conv(p, c->stream);
+    if (up2) launch_conv_up2(p, c->stream);
+    else launch_conv(p, c->stream);
     if (c->prof) {
         char tag[160];
         snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d fused1x1:%d prec%d", cv.ks, stride,
@@ -884,12 +893,19 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
         // weights may change while earlier launches are still reading them
         HIP_OK(hipStreamSynchronize(c->stream));
         if (p.kind == P_CONV) {
-            std::vector<float> packed(p.dev_floats);
+            std::vector<float> packed((size_t)p.ks * p.ks * p.cout * p.cin_pad);
             pack_conv_weight(host, p.cout, p.cin, p.ks, p.cin_pad, packed.data());
+            size_t rows = (size_t)p.ks * p.ks * p.cout;
+            if (p.up_phase) {       // nearest x2 + 3x3 == four 2x2 phase convs on the low-res input
+                std::vector<float> ph(p.dev_floats);
+                make_up2_phase_weights(packed.data(), p.cout, p.cin_pad, ph.data());
+                packed.swap(ph);
+                rows = (size_t)16 * p.cout;
+            }
             HIP_OK(hipMemcpy(p.dev, packed.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
             if (p.keep_host) p.host = packed;
             std::vector<float> sp(p.dev_floats);
-            p.w_unscale = split_conv_weight(packed.data(), (size_t)p.ks * p.ks * p.cout, p.cin_pad, sp.data());
+            p.w_unscale = split_conv_weight(packed.data(), rows, p.cin_pad, sp.data());
             HIP_OK(hipMemcpy(p.dev_split, sp.data(), p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
         } else {
             HIP_OK(hipMemcpy(p.dev, host, p.dev_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -1074,9 +1090,17 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     std::vector<float> packed((size_t)taps * Cout * Cin);
     pack_conv_weight(weight_host, Cout, Cin, ks, Cin, packed.data());
     float w_unscale = 1.0f;
+    size_t rows = (size_t)taps * Cout;
+    if (up2) {
+        if (ks != 3 || stride != 1) return fail("sr3_op_conv2d: up2 needs ks 3, stride 1");
+        std::vector<float> ph((size_t)16 * Cout * Cin);
+        make_up2_phase_weights(packed.data(), Cout, Cin, ph.data());
+        packed.swap(ph);
+        rows = (size_t)16 * Cout;
+    }
     if (c->prec) {
         std::vector<float> sp(packed.size());
-        w_unscale = split_conv_weight(packed.data(), (size_t)taps * Cout, Cin, sp.data());
+        w_unscale = split_conv_weight(packed.data(), rows, Cin, sp.data());
         packed.swap(sp);
     }
     float *dw = nullptr, *db = nullptr, *act = nullptr;
@@ -1103,7 +1127,8 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
     p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
     if (resid_dev) p.resid = unpadded(const_cast<float *>(resid_dev), Cout, p.Hout, p.Wout);
-    launch_conv(p, c->stream);
+    if (up2) launch_conv_up2(p, c->stream);
+    else launch_conv(p, c->stream);
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipFree(dw));
     HIP_OK(hipFree(act));
@@ -1126,7 +1151,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     i0.C = C0; i1.C = C1; act.C = Cin; out.C = res.C = Cout;
     i0.H = i1.H = act.H = Hin; i0.W = i1.W = act.W = Win; out.H = res.H = Ho; out.W = res.W = Wo;
     i0.pad = i1.pad = act.pad = out.pad = res.pad = 1;
-    const size_t n_w = (size_t)ks * ks * Cout * Cin;
+    const size_t n_w = (size_t)(up2 ? 16 : ks * ks) * Cout * Cin;     // up2: 4 phases x 2x2 taps
     float *w, *bias, *sc, *sh, *cb;
     HIP_OK(hipMalloc(&i0.p, i0.floats(B) * 4));
     if (C1) HIP_OK(hipMalloc(&i1.p, i1.floats(B) * 4));
@@ -1151,9 +1176,10 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     p.out = out;
     hipEvent_t e0, e1, e2;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
-    for (int i = 0; i < 2; ++i) launch_conv(p, c->stream);
+    auto go = [&]() { if (up2) launch_conv_up2(p, c->stream); else launch_conv(p, c->stream); };
+    for (int i = 0; i < 2; ++i) go();
     HIP_OK(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; ++i) launch_conv(p, c->stream);
+    for (int i = 0; i < iters; ++i) go();
     HIP_OK(hipEventRecord(e1, c->stream));
     for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, c->prec, act, c->stream);
     HIP_OK(hipEventRecord(e2, c->stream));

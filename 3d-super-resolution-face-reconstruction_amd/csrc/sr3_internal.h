@@ -28,7 +28,12 @@ struct ConvParams {
     TDesc in0, in1;         // in1.p == nullptr if none; same H, W, pad as in0; C multiples of 32
     int B = 0;
     int Hout = 0, Wout = 0;
-    int ks = 3, stride = 1, up2 = 0;
+    int ks = 3, stride = 1, up2 = 0;   // ks 1 | 2 | 3; ks == 2 (stride 1) reads the window (oy+org_y+{0,1}, ox+org_x+{0,1})
+    // sub-pixel phases of the upsample conv (launch_conv_up2): window origin shift in padded
+    // coordinates, and the output pixel written for window (oy, ox) is (oy*out_step + out_oy, ...)
+    int org_y = 0, org_x = 0;
+    int out_step = 1, out_oy = 0, out_ox = 0;
+    int stats_slice0 = 0;              // first statistics slice of this launch
     const float *w = nullptr;          // packed [ks*ks][Cout][Cin]
     // optional fused 1x1 term (ResnetBlock.res_conv, unet.py:102-103,110): out += in2 (*) w2, read at
     // the output pixel; same precision format and (for prec 1) the same weight scale as w
@@ -59,6 +64,15 @@ struct ConvParams {
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
 void launch_conv(const ConvParams &p, hipStream_t s);
+// Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
+// parity (py, px) see only a 2x2 window of the low-resolution input, with the 3x3 taps that land
+// on the same source pixel pre-added (make_up2_phase_weights) — 16 instead of 36 MACs per
+// low-resolution pixel, channel pair and 2x2 output block. p describes the conv at the OUTPUT
+// resolution (Hout, Wout = 2H, 2W; in0 = low-resolution input); p.w = phase weights
+// [4 phases][4 taps][Cout][CinPad]; stats_slices must be 4 * (H*W / conv_tile_m(B*H*W, Cout)).
+void launch_conv_up2(const ConvParams &p, hipStream_t s);
+// packed [9][Cout][CinPad] -> [py*2+px][dy2*2+dx2][Cout][CinPad]
+void make_up2_phase_weights(const float *packed9, int Cout, int CinPad, float *dst);
 // BM of the tile launch_conv will use for this problem (so callers can size / enable fused stats)
 int conv_tile_m(long M, int Cout);
 // number of K-splits launch_conv wants for this problem (1 = none); Cin per tap, multiple of 32
