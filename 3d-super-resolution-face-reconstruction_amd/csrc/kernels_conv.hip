@@ -73,7 +73,7 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// KS: 1 | 2 | 3 (the tap loop is unrolled), UP2: nearest x2 upsample folded into a 9-tap gather (A/B only)
+// KS: 1 | 2 | 3 (the tap loop is unrolled); nearest x2 upsampling never reaches the kernel (launch_conv_up2)
 // Consumer epilogue shared by the conv kernels: split-K partials, or accumulator + bias +
 // FeatureWiseAffine channel bias + residual into the zero-bordered output, plus the fused
 // GroupNorm statistics (per-column fp64 sums left in LDS for the producer threads).
@@ -133,6 +133,24 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
                     const int m = m0 + rbase + j;
                     const float v = acc[mi][ni][4 * rq + j] + add[j];
                     if (m < M && n < Cout) p.out.p[o[j]] = v;
+                    if (p.out_split.p != nullptr) {
+                        // twin in the conv input format: per 32-channel chunk 32 hi halfs | 32 lo halfs.
+                        // Lanes li, li^1 hold neighbouring channels: the even lane stores both hi halfs,
+                        // the odd lane both lo halfs (one 4-byte store per lane instead of two 2-byte ones).
+                        const float g = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                        const _Float16 hi = (_Float16)g;
+                        const _Float16 lo = (_Float16)(g - (float)hi);
+                        const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) |
+                                             ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                        const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+                        const bool odd = li & 1;
+                        const unsigned word = odd ? ((oth >> 16) | (own & 0xFFFF0000u)) : ((own & 0xFFFFu) | (oth << 16));
+                        // Cout % 32 == 0 for every tensor that has a twin, so n < Cout holds for both lanes
+                        if (m < M && n < Cout) {
+                            unsigned *hd = reinterpret_cast<unsigned *>(p.out_split.p + (o[j] & ~31u));
+                            hd[(odd ? 16 : 0) + ((o[j] & 31u) >> 1)] = word;
+                        }
+                    }
                     if (p.stats != nullptr) { st1 += (double)v; st2 = fma((double)v, (double)v, st2); }
                 }
             }
@@ -171,7 +189,7 @@ __device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const f
 // PREC 0: exact f32 (v_mfma_f32_32x32x2_f32); PREC 1: split-f16, 3 x v_mfma_f32_32x32x16_f16
 // NS: LDS pipeline stages (power of two or 3); the DMA of tile k+NS-1 is issued while tile k is
 // multiplied, so NS-2 tiles stay in flight across a barrier (counted vmcnt + raw s_barrier)
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int NS>
+template <int BM, int BN, int WGM, int WGN, int KS, int PREC, int NS>
 __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -208,7 +226,8 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
     const int split = blockIdx.y, nsplit = gridDim.y;
     const int nchunk = Cin / BK;
     const int cb = (int)((long)nchunk * split / nsplit) * BK, ce = (int)((long)nchunk * (split + 1) / nsplit) * BK;
-    const int C2 = (p.in2.p && split == nsplit - 1) ? p.in2.C : 0;          // fused 1x1 term (res_conv)
+    const int C2a = p.in2.p ? p.in2.C : 0, C2t = C2a + (p.in2b.p ? p.in2b.C : 0);
+    const int C2 = split == nsplit - 1 ? C2t : 0;                            // fused 1x1 term (res_conv)
     const int nk = TAPS * ((ce - cb) / BK) + C2 / BK;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -237,8 +256,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         const int tpad = p.in0.pad;
         const int Hp = p.in0.Hp(), Wp = p.in0.Wp();
 
-        unsigned vA0[AR], vA1[AR];            // UP2 == 0: offsets of the window origin (in0 / in1)
-        unsigned vY[UP2 ? AR : 1][3], vX[UP2 ? AR : 1][3];   // UP2 == 1: per-dy / per-dx parts
+        unsigned vA0[AR], vA1[AR];            // offsets of the window origin (in0 / in1)
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
@@ -246,26 +264,17 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             const int rem = m - n * HWo;
             const int oy = rem / p.Wout;
             const int ox = rem - oy * p.Wout;
-            if (UP2) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int sy = ((oy + d - 1) >> 1) + tpad, sx = ((ox + d - 1) >> 1) + tpad;
-                    vY[UP2 ? i : 0][d] = (unsigned)((n * Hp + sy) * Wp) * (unsigned)C0 * 4u;
-                    vX[UP2 ? i : 0][d] = (unsigned)sx * (unsigned)C0 * 4u + schunk16;
-                }
-            } else {
-                const unsigned pixbase = (unsigned)((n * Hp + oy * p.stride - cpad + tpad + p.org_y) * Wp +
-                                                    ox * p.stride - cpad + tpad + p.org_x);
-                vA0[i] = pixbase * (unsigned)C0 * 4u + schunk16;
-                vA1[i] = pixbase * (unsigned)C1 * 4u + schunk16;
-            }
+            const unsigned pixbase = (unsigned)((n * Hp + oy * p.stride - cpad + tpad + p.org_y) * Wp +
+                                                ox * p.stride - cpad + tpad + p.org_x);
+            vA0[i] = pixbase * (unsigned)C0 * 4u + schunk16;
+            vA1[i] = pixbase * (unsigned)C1 * 4u + schunk16;
         });
-        unsigned vB[BR], vB2[BR], vA2[AR];
+        unsigned vB[BR], vB2[BR], vA2[AR], vA2b[AR];
         static_for<BR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
             vB[i] = (unsigned)n * (unsigned)Cin * 4u + schunk16;
-            vB2[i] = (unsigned)n * (unsigned)(p.in2.p ? p.in2.C : 0) * 4u + schunk16;
+            vB2[i] = (unsigned)n * (unsigned)C2t * 4u + schunk16;
         });
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -273,7 +282,8 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             const int n = m / HWo;
             const int rem = m - n * HWo;
             const int oy = rem / p.Wout;
-            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)p.in2.C * 4u + schunk16 : 0u;
+            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)C2a * 4u + schunk16 : 0u;
+            vA2b[i] = C2 > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * p.Wout) * (unsigned)(C2t - C2a) * 4u + schunk16 : 0u;
         });
         const size_t tapstride = (size_t)Cout * Cin;   // floats between taps of the packed weights
 
@@ -292,11 +302,11 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                 float *Ad = smem + (k % NS) * STAGE + w * 256;
                 float *Bd = Ad + BM * ROWF;
                 if (!(p.dbg & 1) || k == 0) {
-                    const char *ab = UP2 ? abase : abase + (size_t)(dy * Wp + dx) * Cs * 4;
+                    const char *ab = abase + (size_t)(dy * Wp + dx) * Cs * 4;
                     if (p.dbg & 2) ab = reinterpret_cast<const char *>(p.in0.p);   // experiment: cache-hot source
                     static_for<AR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        const unsigned vo = UP2 ? vY[UP2 ? i : 0][dy] + vX[UP2 ? i : 0][dx] : (first ? vA0[i] : vA1[i]);
+                        const unsigned vo = first ? vA0[i] : vA1[i];
                         dma16(reinterpret_cast<const float *>(ab + vo), Ad + i * 1024);
                     });
                     const char *wb = (p.dbg & 2) ? reinterpret_cast<const char *>(p.w) : wbase + (size_t)tap * tapstride * 4;
@@ -313,11 +323,12 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         for (int c0 = 0; c0 < C2; c0 += BK) {
             float *Ad = smem + (k % NS) * STAGE + w * 256;
             float *Bd = Ad + BM * ROWF;
-            const char *ab = reinterpret_cast<const char *>(p.in2.p + c0);
+            const bool first2 = c0 < C2a;
+            const char *ab = reinterpret_cast<const char *>(first2 ? p.in2.p + c0 : p.in2b.p + (c0 - C2a));
             const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
             static_for<AR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(ab + vA2[i]), Ad + i * 1024);
+                dma16(reinterpret_cast<const float *>(ab + (first2 ? vA2[i] : vA2b[i])), Ad + i * 1024);
             });
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
     const int SEG = min(W, BM), SEGP = SEG + HALO, nseg = BM / SEG;
     const int rows_a = nseg * SEGP;
     const int nkh = TAPS * (Cin / BK);                 // halo-phase K-steps
-    const int C2 = p.in2.p ? p.in2.C : 0;
+    const int C2a = p.in2.p ? p.in2.C : 0, C2 = C2a + (p.in2b.p ? p.in2b.C : 0);
     const int nk = nkh + C2 / BK;
     const int G = nkh / KS;                             // A groups of the halo phase
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
             vH0[i] = pix * (unsigned)C0 * 4u + schunk16;
             vH1[i] = pix * (unsigned)C1 * 4u + schunk16;
         });
-        unsigned vB[BR], vB2[BR], vA2[AR];
+        unsigned vB[BR], vB2[BR], vA2[AR], vA2b[AR];
         static_for<BR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
@@ -548,7 +559,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
             const int n = m / HWo;
             const int rem = m - n * HWo;
             const int oy = rem / W;
-            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * W) * (unsigned)C2 * 4u + schunk16 : 0u;
+            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * W) * (unsigned)C2a * 4u + schunk16 : 0u;
+            vA2b[i] = C2 > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * W) * (unsigned)(C2 - C2a) * 4u + schunk16 : 0u;
         });
         const size_t tapstride = (size_t)Cout * Cin;
 
@@ -599,11 +611,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
         for (int c0 = 0; c0 < C2; c0 += BK) {
             float *Ad = Aring + (ga & 1) * ASTG + w * 256;
             float *Bd = Bring + (k & 1) * BSTG + w * 256;
-            const char *ab = reinterpret_cast<const char *>(p.in2.p + c0);
+            const bool first2 = c0 < C2a;
+            const char *ab = reinterpret_cast<const char *>(first2 ? p.in2.p + c0 : p.in2b.p + (c0 - C2a));
             const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
             static_for<AR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(ab + vA2[i]), Ad + i * 1024);
+                dma16(reinterpret_cast<const float *>(ab + (first2 ? vA2[i] : vA2b[i])), Ad + i * 1024);
             });
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -722,14 +735,14 @@ static bool halo_ok(const ConvParams &p, int BM, int segmin) {
     const int seg = W < BM ? W : BM;
     if (seg < segmin || (W % seg) || (BM % seg)) return false;
     const long M = (long)p.B * p.Hout * W;
-    return (M % BM) == 0 && (!p.in2.p || (p.in2.C % 32) == 0);
+    return (M % BM) == 0 && (!p.in2.p || (p.in2.C % 32) == 0) && (!p.in2b.p || (p.in2b.C % 32) == 0);
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC, int NS>
+template <int BM, int BN, int WGM, int WGN, int KS, int PREC, int NS>
 void launch_inst2(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t lds = ((size_t)NS * (BM + BN) * ROWF + 2 * BM) * sizeof(float);
-    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, UP2, PREC, NS>;
+    auto kern = conv_igemm_dma_f32<BM, BN, WGM, WGN, KS, PREC, NS>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -740,27 +753,25 @@ void launch_inst2(const ConvParams &p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN, p.splits > 1 ? p.splits : 1), dim3(512), lds, s, p);
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, int UP2, int PREC>
+template <int BM, int BN, int WGM, int WGN, int KS, int PREC>
 void launch_inst(const ConvParams &p, hipStream_t s) {
     // stages per tile shape (A/B in profiles/README.md): the 64x64 tile is used where few blocks
     // are resident (small M), so it gets a 4-deep ring (2 blocks/CU); the larger tiles run 2-3
     // blocks per CU with 2 stages (3 stages x 2 blocks measured the same or slower)
     constexpr int NS = (BM + BN) <= 128 ? 4 : 2;
-    launch_inst2<BM, BN, WGM, WGN, KS, UP2, PREC, NS>(p, s);
+    launch_inst2<BM, BN, WGM, WGN, KS, PREC, NS>(p, s);
 }
 
 template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(const ConvParams &p, hipStream_t s) {
     if (p.prec == 0) {
-        if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0, 0>(p, s);
-        else if (p.ks == 2) launch_inst<BM, BN, WGM, WGN, 2, 0, 0>(p, s);
-        else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1, 0>(p, s);
-        else launch_inst<BM, BN, WGM, WGN, 3, 0, 0>(p, s);
+        if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0>(p, s);
+        else if (p.ks == 2) launch_inst<BM, BN, WGM, WGN, 2, 0>(p, s);
+        else launch_inst<BM, BN, WGM, WGN, 3, 0>(p, s);
     } else {
-        if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 0, 1>(p, s);
-        else if (p.ks == 2) launch_inst<BM, BN, WGM, WGN, 2, 0, 1>(p, s);
-        else if (p.up2) launch_inst<BM, BN, WGM, WGN, 3, 1, 1>(p, s);
-        else launch_inst<BM, BN, WGM, WGN, 3, 0, 1>(p, s);
+        if (p.ks == 1) launch_inst<BM, BN, WGM, WGN, 1, 1>(p, s);
+        else if (p.ks == 2) launch_inst<BM, BN, WGM, WGN, 2, 1>(p, s);
+        else launch_inst<BM, BN, WGM, WGN, 3, 1>(p, s);
     }
 }
 
@@ -789,6 +800,13 @@ __global__ void conv_splitk_reduce_kernel(const ConvParams p, int M, int HWo) {
         if (p.chan_bias) v[j] += p.chan_bias[(size_t)img * p.chan_bias_stride + n + j];
         if (p.resid.p) v[j] += p.resid.p[o + j];
         p.out.p[o + j] = v[j];
+        if (p.out_split.p != nullptr) {
+            const float g = fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+            const _Float16 hi = (_Float16)g;
+            _Float16 *hd = reinterpret_cast<_Float16 *>(p.out_split.p + ((o + j) & ~(size_t)31)) + ((o + j) & 31);
+            hd[0] = hi;
+            hd[32] = (_Float16)(g - (float)hi);
+        }
     }
 }
 
@@ -820,6 +838,7 @@ int conv_splits(long M, int Cout, int Cin) {
 }
 
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
+    if (p_in.up2) { launch_conv_up2(p_in, s); return; }     // weights must be in phase form (make_up2_phase_weights)
     ConvParams p = p_in;
     if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
     const long M = (long)p.B * p.Hout * p.Wout;
@@ -845,8 +864,6 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
 }
 
 void launch_conv_up2(const ConvParams &p_in, hipStream_t s) {
-    static const int gather = getenv("SR3_UP2_GATHER") ? atoi(getenv("SR3_UP2_GATHER")) : 0;   // A/B: old 9-tap gather
-    if (gather) { launch_conv(p_in, s); return; }
     const int H = p_in.Hout / 2, W = p_in.Wout / 2, Cout = p_in.out.C;
     const int Cin = p_in.in0.C + (p_in.in1.p ? p_in.in1.C : 0);
     const long Ml = (long)p_in.B * H * W;

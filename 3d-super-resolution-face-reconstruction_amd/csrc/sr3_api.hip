@@ -77,6 +77,8 @@ struct Module {
     ConvRef conv;
     // workspace (set by ensure_workspace)
     TDesc out;      // module output (zero-bordered)
+    TDesc out_s;    // split-f16 twin of out, written by the producing conv's epilogue in prec 1 when a
+                    // later conv reads this tensor raw (Down/Upsample input, fused res_conv operand); p == null: none
     TDesc rb_out;   // ResBlock output before attention (== out if no attention)
     TDesc act1, act2, h1;   // activated conv inputs and the block1 output (per-shape buffers)
     TDesc up_in;            // M_UP / M_DOWN: split-f16 copy of the raw input (prec 1)
@@ -405,7 +407,14 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     ShapePool acts, h1s, raws;
     const size_t nm = c->mods.size();
     std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
-    std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm);
+    std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm), tw_off(nm);
+    std::vector<char> twin(nm, 0);
+    static const int no_twin = getenv("SR3_NO_TWIN") ? atoi(getenv("SR3_NO_TWIN")) : 0;   // A/B: old copy / raw passes
+    for (size_t i = 0; i < nm && !no_twin; ++i) {
+        const bool skip = (int)i < c->n_downs;                       // consumed raw by an up-path res_conv
+        const Module *nx = i + 1 < nm ? &c->mods[i + 1] : nullptr;
+        twin[i] = skip || (nx && (nx->kind == M_DOWN || nx->kind == M_UP || (nx->kind == M_RES && nx->rb.has_res)));
+    }
     std::vector<int> s_slices(nm, 0);
     uint64_t max_qkv = 0, max_ao = 0, max_part = 0;
     int h = H, w = W;
@@ -462,6 +471,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         }
         const uint64_t n = (uint64_t)B * (h + 2) * (w + 2) * oc;
         out_off[i] = cv.take(n);
+        if (twin[i]) tw_off[i] = cv.take(n);
         rb_off[i] = (m.kind == M_RES && m.rb.attn) ? cv.take(n) : out_off[i];
         cur_c = oc;
     }
@@ -507,6 +517,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         Module &m = c->mods[i];
         m.out = desc(out_off[i], m.oc, m.oh, m.ow, 1);
         m.rb_out = desc(rb_off[i], m.oc, m.oh, m.ow, 1);
+        m.out_s = twin[i] ? desc(tw_off[i], m.oc, m.oh, m.ow, 1) : TDesc();
         m.st_out = m.st_rb = m.st_h1 = StatsRef();
         if (s_slices[i]) {
             m.st_out.p = reinterpret_cast<double *>(c->arena + so_off[i]);
@@ -566,7 +577,7 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
 void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int B, int stride, int up2,
               const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false,
               const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
-              const StatsRef &stats = StatsRef()) {
+              const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc()) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
@@ -576,11 +587,12 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.bias = bias_override ? bias_override : (cv.b >= 0 ? c->params[cv.b].dev : nullptr);
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
     p.resid = resid; p.out = out;
+    if (c->prec) p.out_split = out_split;
     if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
     p.splits = conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
     p.part = c->part;
     if (cv2) {
-        p.in2 = in2;
+        p.in2 = in2; p.in2b = in2b;
         p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;
     }
     c->pbegin(F_CONV);
@@ -600,20 +612,26 @@ TDesc unpadded(float *p, int C, int H, int W) {
 
 // ResnetBlock.forward (unet.py:105-110) + SelfAttention.forward (unet.py:123-142)
 // sx / ss: fused statistics of x / skip (written by the convs that produced them)
-void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TDesc &skip, const StatsRef &ss, int B) {
+// xr / skr: what the fused res_conv reads as x / skip — the fp32 tensors themselves in prec 0, their
+// split twins in prec 1; xr.p == null: no twin, the GroupNorm pass stores the raw concatenation
+void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TDesc &skip, const StatsRef &ss, int B,
+             const TDesc &xr, const TDesc &skr) {
     const ResBlock &rb = m.rb;
     const int h = m.oh, w = m.ow;
     // block1: GN+Swish(x ‖ skip) -> conv3x3 + bias + FeatureWiseAffine bias; the same pass stores
     // the raw concatenation for the fused res_conv
-    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1, sx, ss, rb.has_res ? m.raw1 : kNone);
+    const bool direct = rb.has_res && xr.p && (!skip.p || skr.p);
+    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1, sx, ss, rb.has_res && !direct ? m.raw1 : kNone);
     run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1);
     run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef());
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
     // K-steps | + x as residual when the block keeps its width]
+    const TDesc tw = rb.attn ? kNone : m.out_s;      // with attention the out-projection writes the module output
     if (rb.has_res)
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, m.raw1, &rb.res, rb.fused_bias, m.st_rb);
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, direct ? xr : m.raw1, &rb.res,
+                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone);
     else
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb);
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb, tw);
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
@@ -622,31 +640,34 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
         const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
         c->pend(fl);
         run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out, false, kNone,
-                 nullptr, nullptr, m.st_out);
+                 nullptr, nullptr, m.st_out, m.out_s);
     }
 }
 
 // UNet.forward body (unet.py:240-265): consumes c->x0 and c->cbias, leaves eps NHWC in c->eps
 void run_unet_body(sr3_ctx *c, int B, int H, int W) {
     std::vector<int> feats;
-    TDesc cur = c->x0;
+    TDesc cur = c->x0, cur_s;         // cur_s: split twin of cur (prec 1), null if none
     StatsRef scur;
     const int n_pre = c->n_downs + c->n_mid;
+    static const bool no_direct = getenv("SR3_NO_TWIN") && atoi(getenv("SR3_NO_TWIN"));   // A/B: raw-concatenation pass
     for (int i = 0; i < (int)c->mods.size(); ++i) {
         Module &m = c->mods[i];
         const bool is_up_path = i >= n_pre;
         switch (m.kind) {
         case M_CONV_IN:
-            run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out);
+            run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out, m.out_s);
             break;
         case M_DOWN:
         case M_UP: {
             const int stride = m.kind == M_DOWN ? 2 : 1, up2 = m.kind == M_UP ? 1 : 0;
-            if (c->prec) {   // the raw module output is re-stored in split-f16 form for the fast conv
+            if (c->prec && cur_s.p) {           // the producer left a split-f16 twin: read it directly
+                run_conv(c, cur_s, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s);
+            } else if (c->prec) {               // no twin: re-store the raw input in split-f16 form first
                 c->pbegin(F_GN);
                 launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
                 c->pend();
-                run_conv(c, m.up_in, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out);
+                run_conv(c, m.up_in, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s);
             } else {
                 run_conv(c, cur, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out);
             }
@@ -656,13 +677,16 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
             if (is_up_path) {
                 Module &sk = c->mods[feats.back()];
                 feats.pop_back();
-                run_res(c, m, cur, scur, sk.out, sk.st_out, B);
+                if (c->prec) run_res(c, m, cur, scur, sk.out, sk.st_out, B, cur_s, sk.out_s);
+                else run_res(c, m, cur, scur, sk.out, sk.st_out, B, no_direct ? kNone : cur, sk.out);
             } else {
-                run_res(c, m, cur, scur, kNone, StatsRef(), B);
+                if (c->prec) run_res(c, m, cur, scur, kNone, StatsRef(), B, cur_s, kNone);
+                else run_res(c, m, cur, scur, kNone, StatsRef(), B, no_direct ? kNone : cur, kNone);
             }
             break;
         }
         cur = m.out;
+        cur_s = m.out_s;
         scur = m.st_out;
         if (i < c->n_downs) feats.push_back(i);
     }

@@ -38,7 +38,8 @@ struct ConvParams {
     // optional fused 1x1 term (ResnetBlock.res_conv, unet.py:102-103,110): out += in2 (*) w2, read at
     // the output pixel; same precision format and (for prec 1) the same weight scale as w
     TDesc in2;                         // p == nullptr if none; same H, W as the output
-    const float *w2 = nullptr;         // packed [Cout][in2.C]
+    TDesc in2b;                        // optional second part: the 1x1 input is in2 ‖ in2b (x ‖ skip, unet.py:261)
+    const float *w2 = nullptr;         // packed [Cout][in2.C + in2b.C]
     const float *bias = nullptr;       // [Cout] or null
     const float *chan_bias = nullptr;  // [B][chan_bias_stride] (+ offset applied by caller) or null
     int chan_bias_stride = 0;
@@ -49,6 +50,9 @@ struct ConvParams {
     int stats_slices = 0;
     TDesc resid;            // p == nullptr if none; same geometry as out
     TDesc out;              // C = Cout
+    // optional twin of the output in the split-f16 input format (same geometry as out): lets the
+    // next conv read this tensor directly (Down/Upsample input, fused res_conv operand)
+    TDesc out_split;
     // prec 0: exact f32 MFMA; inputs / weights are fp32.
     // prec 1: split-f16 ("f16x3"): every 32-channel chunk of the inputs and of the packed weights is
     //         stored as 32 hi halfs | 32 lo halfs (x = hi + lo to ~2^-22), the product is
