@@ -35,6 +35,12 @@ CONV_CASES = [
     (5, 4, 4, 256, 256, 256, 1, 1, False),    # res_conv over a concatenation
     (64, 8, 8, 64, 0, 128, 3, 1, False),      # enough blocks for the 128x128 tile
     (40, 16, 16, 64, 0, 64, 3, 1, False),     # 128x64 tile
+    # shapes large enough for the x-halo kernels (f16x3): M >= 65536 pixels
+    (4, 128, 128, 64, 0, 64, 3, 1, False),    # 128x64 halo tile, deep B ring, one row segment per tile
+    (16, 64, 64, 64, 0, 64, 3, 1, False),     # two row segments per tile
+    (64, 32, 32, 64, 32, 64, 3, 1, False),    # four segments, concatenated input (chunk 2 comes from in1)
+    (16, 64, 64, 64, 0, 64, 3, 1, True),      # Upsample as four 2x2 phase convs on the halo kernel
+    (64, 32, 32, 128, 0, 128, 3, 1, False),   # 128x128 halo tile
 ]
 
 
