@@ -100,7 +100,8 @@ def pmc_traffic(precision):
     path = os.path.join(ROOT, "profiles", f"pmc_latest_{precision}.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm"]["conv_igemm"]["bytes_per_launch"]
+            # HBM bytes of the conv family per sampler step (PMC FETCH_SIZE / WRITE_SIZE passes)
+            return json.load(f)["per_step"]["conv_igemm"]["hbm_bytes"]
     except Exception:
         return None
 
@@ -186,11 +187,15 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         roof = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": pmc_traffic(args.precision),
-            "note": ("achieved = algorithmic conv FLOPs / HIP-event time; in f16x3 every algorithmic MAC costs 3 "
-                     "MFMA MACs, so matrix-pipe utilisation is 3x frac") if args.precision == "f16x3" else
-                    "achieved = algorithmic conv FLOPs / HIP-event time on the exact-f32 MFMA",
-            "kernel": "conv_igemm_dma_f32<BM,BN,...> (all tile shapes)", "launches_per_step": n / K,
+            "frac": achieved / peak,
+            "traffic": (pmc_traffic(args.precision) / (n / K)) if pmc_traffic(args.precision) else None,
+            "note": ("achieved = algorithmic conv FLOPs (the reference's conv arithmetic, SURVEY 8d) / HIP-event "
+                     "time per logical conv; the Upsample convs execute 16/36 of their algorithmic MACs (sub-pixel "
+                     "phases). " +
+                     ("In f16x3 every executed MAC costs 3 MFMA MACs (matrix-pipe busy: see profiles/README.md)."
+                      if args.precision == "f16x3" else "Exact-f32 MFMA.")),
+            "kernel": "conv family: conv3x3_halo_h3<...> + conv_igemm_dma_f32<...> (all tile shapes)",
+            "launches_per_step": n / K,
             "avg_launch_ms": avg_ms, "flop_per_launch": conv["flops"] / n,
             "family_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
             "whole_step_frac": (B * graph.flops_per_image(cfg, r, r) / sec_per_step / 1e12) / peak,

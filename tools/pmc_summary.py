@@ -58,6 +58,15 @@ def main(src, prefix):
         hbm[fam] = {"read_bytes_per_launch": 2 * f["sum"] * 1024 / n, "write_bytes_per_launch": w["sum"] * 1024 / max(1, w["launches"])}
         hbm[fam]["bytes_per_launch"] = hbm[fam]["read_bytes_per_launch"] + hbm[fam]["write_bytes_per_launch"]
     out["hbm"] = hbm
+    # one ddpm_update launch per sampler step: per-step totals (a logical conv of the engine can be
+    # several device launches: 4 sub-pixel phases of an upsample conv, split-K + reduce)
+    steps = max(1, out["kernel_trace_ms"].get("update", {}).get("launches", 1))
+    out["steps"] = steps
+    out["per_step"] = {fam: {"ms": v["total_ms"] / steps, "device_launches": v["launches"] / steps,
+                             "hbm_bytes": (hbm.get(fam, {}).get("bytes_per_launch", 0.0) *
+                                           out.get("FETCH_SIZE_KiB", {}).get(fam, {}).get("launches", 0)) /
+                                          max(1, out["kernel_trace_ms"].get("update", {}).get("launches", 1))}
+                       for fam, v in out["kernel_trace_ms"].items()}
     sq = defaultdict(lambda: defaultdict(float))
     for r in load(f"{src}/p_sq", "counter_collection.csv"):
         sq[family(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
