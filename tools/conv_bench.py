@@ -33,6 +33,8 @@ if __name__ == "__main__":
     ap.add_argument("--only", type=str, default="", help="comma list of shape indices")
     ap.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3"])
     args = ap.parse_args()
+    if os.environ.get("SR3_LIB"):       # timing experiments with an alternative build of the library
+        importlib.import_module(PKG + "._lib").LIB_PATH = os.path.abspath(os.environ["SR3_LIB"])
     synth = importlib.import_module(PKG + ".synth")
     Engine = importlib.import_module(PKG + ".engine").Engine
     e = Engine(synth.tiny_unet_config(), 0)
