@@ -120,6 +120,7 @@ struct sr3_ctx {
     char *arena = nullptr;
     uint64_t arena_bytes = 0;
     TDesc x0;                   // [B][H+2][W+2][in_pad]: cond ‖ x ‖ zero pad (UNet input = sampler state)
+    TDesc x0s;                  // split-f16 copy of x0 for the first conv (prec 1)
     TDesc eps;                  // [B][H][W][out_channel]
     TDesc final_act;            // activated input of final_conv
     float *qkvb = nullptr, *aob = nullptr;
@@ -497,6 +498,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t o_fa = acts.get(cv, B, c->final_gn.C, H, W);
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t o_x0 = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
+    const uint64_t o_x0s = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
     const uint64_t o_part = cv.take(max_part);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
@@ -544,6 +546,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         }
     }
     c->x0 = desc(o_x0, c->in_pad, H, W, 1);
+    c->x0s = desc(o_x0s, c->in_pad, H, W, 1);
     c->eps = desc(o_eps, g.out_channel, H, W, 0);
     c->final_act = desc(o_fa, c->final_gn.C, H, W, 1);
     c->qkvb = at(o_qkv); c->aob = at(o_ao);
@@ -656,7 +659,15 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
         const bool is_up_path = i >= n_pre;
         switch (m.kind) {
         case M_CONV_IN:
-            run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out, m.out_s);
+            if (c->prec) {      // the 6 (of 32 padded) input channels in split-f16 form: the first conv then runs
+                                // on the fast path too instead of 9 mostly-zero K-steps of f32 MFMA
+                c->pbegin(F_GN);
+                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream);
+                c->pend();
+                run_conv(c, c->x0s, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s);
+            } else {
+                run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out, m.out_s);
+            }
             break;
         case M_DOWN:
         case M_UP: {
