@@ -41,6 +41,8 @@ CONV_CASES = [
     (64, 32, 32, 64, 32, 64, 3, 1, False),    # four segments, concatenated input (chunk 2 comes from in1)
     (16, 64, 64, 64, 0, 64, 3, 1, True),      # Upsample as four 2x2 phase convs on the halo kernel
     (64, 32, 32, 128, 0, 128, 3, 1, False),   # 128x128 halo tile
+    (64, 8, 8, 512, 0, 512, 3, 1, False),     # small M, deep K (the 8x8 level): 64x64 tile, 4-stage ring
+    (64, 16, 16, 256, 0, 256, 3, 2, False),   # Downsample at full batch
 ]
 
 
