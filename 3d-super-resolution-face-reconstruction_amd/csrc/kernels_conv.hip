@@ -74,6 +74,12 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 }
 
 // KS: 1 | 2 | 3 (the tap loop is unrolled); nearest x2 upsampling never reaches the kernel (launch_conv_up2)
+// residual element o (= pixel * C + channel) of a tensor stored in the split-f16 format: hi + lo
+__device__ __forceinline__ float load_split(const float *base, unsigned o) {
+    const _Float16 *hp = reinterpret_cast<const _Float16 *>(base + (o & ~31u)) + (o & 31u);
+    return (float)hp[0] + (float)hp[32];
+}
+
 // Consumer epilogue shared by the conv kernels: split-K partials, or accumulator + bias +
 // FeatureWiseAffine channel bias + residual into the zero-bordered output, plus the fused
 // GroupNorm statistics (per-column fp64 sums left in LDS for the producer threads).
@@ -121,7 +127,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
                 }
                 if (p.resid.p != nullptr) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) add[j] += p.resid.p[o[j]];
+                    for (int j = 0; j < 4; ++j) add[j] += p.resid_split ? load_split(p.resid.p, o[j]) : p.resid.p[o[j]];
                 }
                 if (p.chan_bias != nullptr) {
 #pragma unroll
@@ -132,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
                 for (int j = 0; j < 4; ++j) {
                     const int m = m0 + rbase + j;
                     const float v = acc[mi][ni][4 * rq + j] + add[j];
-                    if (m < M && n < Cout) p.out.p[o[j]] = v;
+                    if (m < M && n < Cout && p.out_f32) p.out.p[o[j]] = v;
                     if (p.out_split.p != nullptr) {
                         // twin in the conv input format: per 32-channel chunk 32 hi halfs | 32 lo halfs.
                         // Lanes li, li^1 hold neighbouring channels: the even lane stores both hi halfs,
@@ -194,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
             }
             if (p.resid.p != nullptr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) add[j] += p.resid.p[o[j]];
+                for (int j = 0; j < 4; ++j) add[j] += p.resid_split ? load_split(p.resid.p, o[j]) : p.resid.p[o[j]];
             }
             if (p.chan_bias != nullptr) {
 #pragma unroll
@@ -205,7 +211,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
             for (int j = 0; j < 4; ++j) {
                 const int m = m0 + rbase + j;
                 const float v = acc[mt][nt][j] + add[j];
-                if (m < M && n < Cout) p.out.p[o[j]] = v;
+                if (m < M && n < Cout && p.out_f32) p.out.p[o[j]] = v;
                 if (p.out_split.p != nullptr) {     // split-f16 twin, see conv_epilogue_impl
                     const float g = fminf(fmaxf(v, -65504.0f), 65504.0f);
                     const _Float16 hi = (_Float16)g;
@@ -952,8 +958,8 @@ __global__ void conv_splitk_reduce_kernel(const ConvParams p, int M, int HWo) {
     for (int j = 0; j < 4; ++j) {
         if (p.bias) v[j] += p.bias[n + j];
         if (p.chan_bias) v[j] += p.chan_bias[(size_t)img * p.chan_bias_stride + n + j];
-        if (p.resid.p) v[j] += p.resid.p[o + j];
-        p.out.p[o + j] = v[j];
+        if (p.resid.p) v[j] += p.resid_split ? load_split(p.resid.p, (unsigned)(o + j)) : p.resid.p[o + j];
+        if (p.out_f32) p.out.p[o + j] = v[j];
         if (p.out_split.p != nullptr) {
             const float g = fminf(fmaxf(v[j], -65504.0f), 65504.0f);
             const _Float16 hi = (_Float16)g;

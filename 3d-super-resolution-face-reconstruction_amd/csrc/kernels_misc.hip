@@ -198,7 +198,7 @@ template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, const TDesc out,
-                                                       const TDesc raw) {
+                                                       const TDesc raw, const int in_split) {
     // a thread owns 8 consecutive channels of one pixel (two 16-B loads, 16-B stores);
     // grid: x = chunks of (pixel-in-row, channel octet), y = n * H + row
     const int C0 = in0.C, C = out.C, C8 = C >> 3;
@@ -207,11 +207,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
     if (item >= out.W * C8) return;
     const int x = item / C8;
     const int c = (item - x * C8) << 3;
-    const float *src = (c < C0) ? in0.p + in0.pix(n, y, x) * C0 + c
-                                : in1.p + in1.pix(n, y, x) * in1.C + (c - C0);
-    const float4 v0 = *reinterpret_cast<const float4 *>(src);
-    const float4 v1 = *reinterpret_cast<const float4 *>(src + 4);
-    float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    // in_split bit 0 / 1: in0 / in1 is stored in the split-f16 format (a conv wrote only the twin of
+    // its output): x = hi + lo, exact to ~2^-22 |x|
+    const bool first = c < C0;
+    const int cl = first ? c : c - C0;
+    const float *pixp = first ? in0.p + in0.pix(n, y, x) * C0 : in1.p + in1.pix(n, y, x) * in1.C;
+    float f[8];
+    if ((in_split >> (first ? 0 : 1)) & 1) {
+        const _Float16 *hp = reinterpret_cast<const _Float16 *>(pixp + (cl & ~31)) + (cl & 31);
+        const h16x8 hi = *reinterpret_cast<const h16x8 *>(hp), lo = *reinterpret_cast<const h16x8 *>(hp + 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)hi[j] + (float)lo[j];
+    } else {
+        const float4 v0 = *reinterpret_cast<const float4 *>(pixp + cl);
+        const float4 v1 = *reinterpret_cast<const float4 *>(pixp + cl + 4);
+        f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+    }
     if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f);
     if (MODE != 0) {
         const float *scp = scale + (size_t)n * C + c, *shp = shift + (size_t)n * C + c;
@@ -232,10 +243,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
 } // namespace
 
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw) {
+                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw, int in_split) {
     const int items = out.W * (out.C >> 3);
     const dim3 grid((items + 255) / 256, B * out.H);
-#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw)
+#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split)
     if (split) {
         if (mode == 0) SR3_GA(0, 1); else if (mode == 1) SR3_GA(1, 1); else SR3_GA(2, 1);
     } else {

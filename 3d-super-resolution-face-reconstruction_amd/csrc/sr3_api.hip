@@ -77,6 +77,7 @@ struct Module {
     ConvRef conv;
     // workspace (set by ensure_workspace)
     TDesc out;      // module output (zero-bordered)
+    bool so_now = false;   // this forward: out was written ONLY as out_s (prec 1, split-only mode)
     TDesc out_s;    // split-f16 twin of out, written by the producing conv's epilogue in prec 1 when a
                     // later conv reads this tensor raw (Down/Upsample input, fused res_conv operand); p == null: none
     TDesc rb_out;   // ResBlock output before attention (== out if no attention)
@@ -114,6 +115,7 @@ struct sr3_ctx {
     int prec = 0;       // 0 exact f32 MFMA, 1 split-f16 (f16x3) for the 3x3 / activated-input convs
     bool fused_dirty = true;   // fused bias / common weight scales need (re)building
     bool no_fused_stats = false;   // SR3_NO_FUSED_STATS=1: always run the statistics kernel (A/B testing)
+    bool all_fused = false;        // every GroupNorm of the current workspace gets its statistics from a conv epilogue
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -515,6 +517,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     auto desc = [&](uint64_t o, int C, int hh, int ww, int pad) {
         TDesc d; d.p = at(o); d.C = C; d.H = hh; d.W = ww; d.pad = pad; return d;
     };
+    bool all_fused = true;
     for (size_t i = 0; i < nm; ++i) {
         Module &m = c->mods[i];
         m.out = desc(out_off[i], m.oc, m.oh, m.ow, 1);
@@ -537,6 +540,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
                 m.st_out = StatsRef();
             }
         }
+        if (!m.st_out.p || (m.kind == M_RES && (!m.st_h1.p || !m.st_rb.p))) all_fused = false;
         if (m.kind == M_UP || m.kind == M_DOWN) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);
         if (m.kind == M_RES) {
             m.act1 = desc(a1_off[i], m.rb.cin, m.oh, m.ow, 1);
@@ -553,6 +557,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     c->part = max_part ? at(o_part) : nullptr;
     c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
     c->temb = at(o_te); c->cbias = at(o_cb);
+    c->all_fused = all_fused;
     c->wB = B; c->wH = H; c->wW = W;
     return 0;
 }
@@ -564,7 +569,7 @@ const TDesc kNone{};
 
 // GroupNorm statistics + apply (+Swish) (+concat) -> activated, zero-bordered conv input
 void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act,
-                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc()) {
+                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc(), int in_split = 0) {
     c->pbegin(F_GN);
     if (sa.p && (!b.p || sb.p) && !c->no_fused_stats)
         launch_groupnorm_finalize(sa, a.C, sb, b.p ? b.C : 0, B, a.H * a.W, c->cfg.norm_groups,
@@ -572,7 +577,7 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
     else
         launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
                                 c->gpart, c->gscale, c->gshift, c->stream);
-    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw);
+    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split);
     c->pend();
 }
 
@@ -580,7 +585,8 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
 void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int B, int stride, int up2,
               const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false,
               const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
-              const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc()) {
+              const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc(),
+              bool out_f32 = true, bool resid_split = false) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
@@ -591,6 +597,8 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
     p.resid = resid; p.out = out;
     if (c->prec) p.out_split = out_split;
+    p.out_f32 = (out_f32 || !p.out_split.p) ? 1 : 0;
+    p.resid_split = resid_split ? 1 : 0;
     if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
     p.splits = conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
     p.part = c->part;
@@ -617,14 +625,17 @@ TDesc unpadded(float *p, int C, int H, int W) {
 // sx / ss: fused statistics of x / skip (written by the convs that produced them)
 // xr / skr: what the fused res_conv reads as x / skip — the fp32 tensors themselves in prec 0, their
 // split twins in prec 1; xr.p == null: no twin, the GroupNorm pass stores the raw concatenation
+// x_so / sk_so: x / skip exist ONLY as their split twins xr / skr this forward; out_so: write this
+// block's output only as its twin
 void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TDesc &skip, const StatsRef &ss, int B,
-             const TDesc &xr, const TDesc &skr) {
+             const TDesc &xr, const TDesc &skr, bool x_so = false, bool sk_so = false, bool out_so = false) {
     const ResBlock &rb = m.rb;
     const int h = m.oh, w = m.ow;
     // block1: GN+Swish(x ‖ skip) -> conv3x3 + bias + FeatureWiseAffine bias; the same pass stores
     // the raw concatenation for the fused res_conv
     const bool direct = rb.has_res && xr.p && (!skip.p || skr.p);
-    run_gn_act(c, x, skip, rb.gn1, B, 2, m.act1, sx, ss, rb.has_res && !direct ? m.raw1 : kNone);
+    run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, m.act1, sx, ss,
+               rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0));
     run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1);
     run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef());
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
@@ -632,9 +643,10 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     const TDesc tw = rb.attn ? kNone : m.out_s;      // with attention the out-projection writes the module output
     if (rb.has_res)
         run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, direct ? xr : m.raw1, &rb.res,
-                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone);
+                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone, !out_so);
     else
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb, tw);
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x_so ? xr : x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb,
+                 tw, kNone, !out_so, x_so);
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
@@ -651,7 +663,13 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
 void run_unet_body(sr3_ctx *c, int B, int H, int W) {
     std::vector<int> feats;
     TDesc cur = c->x0, cur_s;         // cur_s: split twin of cur (prec 1), null if none
+    bool cur_so = false;              // cur exists only as cur_s
     StatsRef scur;
+    // split-only mode: a module output that has a twin is written ONLY as the twin (4 instead of 8
+    // bytes per element); GroupNorm apply and residual adds read hi + lo. Needs every GroupNorm to get
+    // its statistics from a conv epilogue (the fallback statistics kernel reads fp32 tensors).
+    static const bool so_off = getenv("SR3_NO_SPLIT_ONLY") && atoi(getenv("SR3_NO_SPLIT_ONLY"));
+    const bool so_mode = c->prec && c->all_fused && !c->no_fused_stats && !so_off;
     const int n_pre = c->n_downs + c->n_mid;
     static const bool no_direct = getenv("SR3_NO_TWIN") && atoi(getenv("SR3_NO_TWIN"));   // A/B: raw-concatenation pass
     for (int i = 0; i < (int)c->mods.size(); ++i) {
@@ -664,7 +682,8 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
                 c->pbegin(F_GN);
                 launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream);
                 c->pend();
-                run_conv(c, c->x0s, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s);
+                run_conv(c, c->x0s, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s,
+                         kNone, !(so_mode && m.out_s.p));
             } else {
                 run_conv(c, cur, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, false, kNone, nullptr, nullptr, m.st_out, m.out_s);
             }
@@ -673,7 +692,8 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
         case M_UP: {
             const int stride = m.kind == M_DOWN ? 2 : 1, up2 = m.kind == M_UP ? 1 : 0;
             if (c->prec && cur_s.p) {           // the producer left a split-f16 twin: read it directly
-                run_conv(c, cur_s, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s);
+                run_conv(c, cur_s, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s,
+                         kNone, !(so_mode && m.out_s.p));
             } else if (c->prec) {               // no twin: re-store the raw input in split-f16 form first
                 c->pbegin(F_GN);
                 launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
@@ -688,16 +708,20 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
             if (is_up_path) {
                 Module &sk = c->mods[feats.back()];
                 feats.pop_back();
-                if (c->prec) run_res(c, m, cur, scur, sk.out, sk.st_out, B, cur_s, sk.out_s);
+                if (c->prec) run_res(c, m, cur, scur, sk.out, sk.st_out, B, cur_s, sk.out_s, cur_so, sk.so_now,
+                                     so_mode && m.out_s.p && !m.rb.attn);
                 else run_res(c, m, cur, scur, sk.out, sk.st_out, B, no_direct ? kNone : cur, sk.out);
             } else {
-                if (c->prec) run_res(c, m, cur, scur, kNone, StatsRef(), B, cur_s, kNone);
+                if (c->prec) run_res(c, m, cur, scur, kNone, StatsRef(), B, cur_s, kNone, cur_so, false,
+                                     so_mode && m.out_s.p && !m.rb.attn);
                 else run_res(c, m, cur, scur, kNone, StatsRef(), B, no_direct ? kNone : cur, kNone);
             }
             break;
         }
+        m.so_now = so_mode && m.out_s.p && !(m.kind == M_RES && m.rb.attn);
         cur = m.out;
         cur_s = m.out_s;
+        cur_so = m.so_now;
         scur = m.st_out;
         if (i < c->n_downs) feats.push_back(i);
     }

@@ -49,10 +49,12 @@ struct ConvParams {
     double *stats = nullptr;
     int stats_slices = 0;
     TDesc resid;            // p == nullptr if none; same geometry as out
+    int resid_split = 0;    // 1: resid is stored in the split-f16 format (hi + lo), not fp32
     TDesc out;              // C = Cout
     // optional twin of the output in the split-f16 input format (same geometry as out): lets the
     // next conv read this tensor directly (Down/Upsample input, fused res_conv operand)
     TDesc out_split;
+    int out_f32 = 1;        // 0: only out_split is written (out.p then only provides the geometry)
     // prec 0: exact f32 MFMA; inputs / weights are fp32.
     // prec 1: split-f16 ("f16x3"): every 32-channel chunk of the inputs and of the packed weights is
     //         stored as 32 hi halfs | 32 lo halfs (x = hi + lo to ~2^-22), the product is
@@ -102,8 +104,10 @@ void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, i
 // 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format).
 // raw (optional, p != nullptr): additionally stores the un-normalised concatenation in the same
 // format (the input of a fused res_conv).
+// in_split: bit 0 / bit 1 = in0 / in1 is itself stored in the split-f16 format (split-only tensors)
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw = TDesc());
+                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw = TDesc(),
+                     int in_split = 0);
 // common power-of-two scale for several weight tensors: returns k with max|w| * 2^k in [1024, 2048)
 int split_scale_exponent(const float *packed, size_t n);
 float split_conv_weight_k(const float *packed, size_t rows, int CinPad, int k, float *dst);
