@@ -68,6 +68,11 @@ struct ResBlock {
     int nf_off = 0;  // offset into the concatenated FeatureWiseAffine output
     bool has_res = false, attn = false;
     float *fused_bias = nullptr;   // has_res: conv2 bias + res_conv bias (the fused launch adds both)
+    // identity skip (dim == dim_out) of a narrow block in split-f16 mode: `h + x` runs as cout / 32 extra
+    // K-steps of conv2 over the raw x twin with the matrix 2^k * I (exact: 2^k is a half, x = hi + lo),
+    // instead of a per-element gather of x in the epilogue — the K loop of these 64/128-channel layers
+    // is short and the gather cost more than the two or four extra K-steps
+    float *ident_w = nullptr;      // split-f16 [cout][cout], rebuilt whenever conv2's scale changes
 };
 
 enum ModKind { M_CONV_IN, M_RES, M_DOWN, M_UP };
@@ -586,7 +591,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
               const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false,
               const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
               const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc(),
-              bool out_f32 = true, bool resid_split = false) {
+              bool out_f32 = true, bool resid_split = false, const float *w2_raw = nullptr) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
@@ -605,6 +610,9 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     if (cv2) {
         p.in2 = in2; p.in2b = in2b;
         p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;
+    } else if (w2_raw && p.prec) {
+        p.in2 = in2;                    // identity skip as extra K-steps (ResBlock::ident_w)
+        p.w2 = w2_raw;
     }
     c->pbegin(F_CONV);
     if (up2) launch_conv_up2(p, c->stream);
@@ -633,6 +641,7 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     const int h = m.oh, w = m.ow;
     // block1: GN+Swish(x ‖ skip) -> conv3x3 + bias + FeatureWiseAffine bias; the same pass stores
     // the raw concatenation for the fused res_conv
+    static const bool no_ident = getenv("SR3_NO_IDENT") && atoi(getenv("SR3_NO_IDENT"));   // A/B: epilogue gather
     const bool direct = rb.has_res && xr.p && (!skip.p || skr.p);
     run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, m.act1, sx, ss,
                rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0));
@@ -644,6 +653,9 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     if (rb.has_res)
         run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, direct ? xr : m.raw1, &rb.res,
                  rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone, !out_so);
+    else if (c->prec && rb.ident_w && xr.p && !no_ident)
+        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, xr, nullptr, nullptr, m.st_rb,
+                 tw, kNone, !out_so, false, rb.ident_w);
     else
         run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x_so ? xr : x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb,
                  tw, kNone, !out_so, x_so);
@@ -747,6 +759,17 @@ void run_embed(sr3_ctx *c, const float *nl, int stride, int B) {
 int prepare_fused(sr3_ctx *c) {
     if (!c->fused_dirty) return 0;
     HIP_OK(hipStreamSynchronize(c->stream));
+    for (auto &m : c->mods) {
+        if (m.kind != M_RES || m.rb.has_res || m.rb.cout > 128 || (m.rb.cout % 32)) continue;
+        ResBlock &rb = m.rb;
+        const size_t n = (size_t)rb.cout * rb.cout;
+        std::vector<float> buf(n, 0.f);
+        _Float16 *h = reinterpret_cast<_Float16 *>(buf.data());
+        const float v = 1.0f / c->params[rb.c2.w].w_unscale;        // 2^k of conv2's split weights
+        for (int o = 0; o < rb.cout; ++o) h[((size_t)o * rb.cout + (o & ~31)) * 2 + (o & 31)] = (_Float16)v;
+        if (!rb.ident_w) HIP_OK(hipMalloc(&rb.ident_w, n * sizeof(float)));
+        HIP_OK(hipMemcpy(rb.ident_w, buf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
     for (auto &m : c->mods) {
         if (m.kind != M_RES || !m.rb.has_res) continue;
         ResBlock &rb = m.rb;
@@ -885,8 +908,10 @@ void sr3_destroy(sr3_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &m : c->mods)
+    for (auto &m : c->mods) {
         if (m.rb.fused_bias) (void)hipFree(m.rb.fused_bias);
+        if (m.rb.ident_w) (void)hipFree(m.rb.ident_w);
+    }
     for (auto &p : c->params) {
         if (p.owns && p.dev) (void)hipFree(p.dev);
         if (p.dev_split) (void)hipFree(p.dev_split);
