@@ -182,11 +182,18 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
                                                 int wn, int l16, int q) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     const int Cout = p.out.C;
+    const int img0 = rowimg[wm * WM];
+    const bool one_img = img0 == rowimg[wm * WM + WM - 1];      // rows are consecutive pixels: first == last image
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + wn * WN + nt * 16 + l16;
         const int nc = min(n, Cout - 1);
-        const float bs = p.bias ? p.bias[nc] : 0.f;
+        float bs = p.bias ? p.bias[nc] : 0.f;
+        // FeatureWiseAffine bias: one value per (image, channel). When all rows of this wave's tile
+        // belong to one image (every level but the 8x8 one) it joins the column bias; otherwise it
+        // is gathered per row.
+        const bool cb_rows = p.chan_bias != nullptr && !one_img;
+        if (p.chan_bias != nullptr && one_img) bs += p.chan_bias[(size_t)img0 * p.chan_bias_stride + nc];
         double st1 = 0.0, st2 = 0.0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -202,7 +209,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
 #pragma unroll
                 for (int j = 0; j < 4; ++j) add[j] += p.resid_split ? load_split(p.resid.p, o[j]) : p.resid.p[o[j]];
             }
-            if (p.chan_bias != nullptr) {
+            if (cb_rows) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     add[j] += p.chan_bias[(size_t)rowimg[rbase + j] * p.chan_bias_stride + nc];
