@@ -77,23 +77,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const TDesc in0, const 
     }
 }
 
-// two partial sources (the halves of a concatenation may come from convs with different tilings)
+// two partial sources (the halves of a concatenation may come from convs with different tilings).
+// grid (image, group quarter): a block reduces groups/GQ groups with 256 / (groups/GQ) slice lanes
+// each, so the 128-slice tensors of the 128x128 level are read by 4x as many threads.
+constexpr int GN_FIN_GQ = 4;
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restrict__ part0, int C0, int slices0,
                                                           const double *__restrict__ part1, int C1, int slices1,
                                                           int HW, int groups, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
                                                           float *__restrict__ scale, float *__restrict__ shift) {
-    extern __shared__ float sm[];  // mean[groups], rstd[groups]
+    __shared__ float s_mean[256], s_rstd[256];
     __shared__ double ra[256], rb[256];
     const int n = blockIdx.x, t = threadIdx.x;
     const int C = C0 + C1, Cg = C / groups;
+    const int gq = (groups + gridDim.y - 1) / gridDim.y;          // groups of this block
+    const int g0 = blockIdx.y * gq, g1 = min(groups, g0 + gq);
     // (group, slice lane): 256 / gpp slice lanes per group, gpp groups per pass
-    const int gpp = min(groups, 256);
+    const int gpp = min(gq, 256);
     const int lanes = 256 / gpp;
-    for (int gbase = 0; gbase < groups; gbase += gpp) {
+    for (int gbase = g0; gbase < g1; gbase += gpp) {
         const int g = gbase + (t % gpp), sl0 = t / gpp;
         double a = 0, b = 0;
-        if (g < groups && sl0 < lanes) {
+        if (g < g1 && sl0 < lanes) {
             for (int cc = 0; cc < Cg; ++cc) {
                 const int c = g * Cg + cc;
                 const bool first = c < C0;
@@ -107,23 +112,24 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
         }
         ra[t] = a; rb[t] = b;
         __syncthreads();
-        if (t < gpp && gbase + t < groups) {
+        if (t < gpp && gbase + t < g1) {
             double sa = 0, sb = 0;
             for (int l = 0; l < lanes; ++l) { sa += ra[l * gpp + t]; sb += rb[l * gpp + t]; }
             const double cnt = (double)Cg * HW;
             const double mean = sa / cnt;
             const double var = fmax(sb / cnt - mean * mean, 0.0);
-            sm[gbase + t] = (float)mean;
-            sm[groups + gbase + t] = 1.0f / sqrtf((float)var + eps);
+            s_mean[t] = (float)mean;
+            s_rstd[t] = 1.0f / sqrtf((float)var + eps);
         }
         __syncthreads();
-    }
-    __syncthreads();
-    for (int c = t; c < C; c += blockDim.x) {
-        const int g = c / Cg;
-        const float sc = sm[groups + g] * gamma[c];
-        scale[(size_t)n * C + c] = sc;
-        shift[(size_t)n * C + c] = beta[c] - sm[g] * sc;
+        const int c_lo = gbase * Cg, c_hi = min(g1, gbase + gpp) * Cg;
+        for (int c = c_lo + t; c < c_hi; c += blockDim.x) {
+            const int gl = c / Cg - gbase;
+            const float sc = s_rstd[gl] * gamma[c];
+            scale[(size_t)n * C + c] = sc;
+            shift[(size_t)n * C + c] = beta[c] - s_mean[gl] * sc;
+        }
+        __syncthreads();
     }
 }
 
@@ -150,14 +156,14 @@ void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int grou
     const int C = in0.C + (in1.p ? in1.C : 0);
     double *dpart = reinterpret_cast<double *>(part);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, in1, slices, dpart);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, dpart, C, slices,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, groups % GN_FIN_GQ ? 1 : GN_FIN_GQ), dim3(256), 0, s, dpart, C, slices,
                        (const double *)nullptr, 0, 0, HW, groups, gamma, beta, eps, scale, shift);
 }
 
 void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, int C1, int B, int HW, int groups,
                                const float *gamma, const float *beta, float eps, float *scale, float *shift,
                                hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * groups * sizeof(float), s, s0.p, C0, s0.slices,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, groups % GN_FIN_GQ ? 1 : GN_FIN_GQ), dim3(256), 0, s, s0.p, C0, s0.slices,
                        s1.p, C1, s1.slices, HW, groups, gamma, beta, eps, scale, shift);
 }
 
