@@ -396,23 +396,36 @@ __global__ __launch_bounds__(256) void noise_embed_kernel(const EmbedParams p) {
     __syncthreads();
     for (int j = t; j < hid; j += blockDim.x) {
         float a = p.b1[j];
-        const float *w = p.w1 + (size_t)j * dim;
-        for (int k = 0; k < dim; ++k) a = fmaf(w[k], pe[k], a);
+        const float4 *w = reinterpret_cast<const float4 *>(p.w1 + (size_t)j * dim);
+        const float4 *v = reinterpret_cast<const float4 *>(pe);
+        // 16-byte loads, same k order as a scalar loop (fmaf chain): results unchanged
+        for (int k = 0; k < dim / 4; ++k) {
+            const float4 ww = w[k], vv = v[k];
+            a = fmaf(ww.x, vv.x, a); a = fmaf(ww.y, vv.y, a); a = fmaf(ww.z, vv.z, a); a = fmaf(ww.w, vv.w, a);
+        }
         h[j] = a / (1.0f + expf(-a));
     }
     __syncthreads();
     for (int j = t; j < dim; j += blockDim.x) {
         float a = p.b2[j];
-        const float *w = p.w2 + (size_t)j * hid;
-        for (int k = 0; k < hid; ++k) a = fmaf(w[k], h[k], a);
+        const float4 *w = reinterpret_cast<const float4 *>(p.w2 + (size_t)j * hid);
+        const float4 *v = reinterpret_cast<const float4 *>(h);
+        for (int k = 0; k < hid / 4; ++k) {
+            const float4 ww = w[k], vv = v[k];
+            a = fmaf(ww.x, vv.x, a); a = fmaf(ww.y, vv.y, a); a = fmaf(ww.z, vv.z, a); a = fmaf(ww.w, vv.w, a);
+        }
         te[j] = a;
         if (p.temb) p.temb[(size_t)n * dim + j] = a;
     }
     __syncthreads();
     for (int j = t; j < p.total; j += blockDim.x) {
         float a = p.nfb[j];
-        const float *w = p.nfw + (size_t)j * dim;
-        for (int k = 0; k < dim; ++k) a = fmaf(w[k], te[k], a);
+        const float4 *w = reinterpret_cast<const float4 *>(p.nfw + (size_t)j * dim);
+        const float4 *v = reinterpret_cast<const float4 *>(te);
+        for (int k = 0; k < dim / 4; ++k) {
+            const float4 ww = w[k], vv = v[k];
+            a = fmaf(ww.x, vv.x, a); a = fmaf(ww.y, vv.y, a); a = fmaf(ww.z, vv.z, a); a = fmaf(ww.w, vv.w, a);
+        }
         p.chan_bias[(size_t)n * p.total + j] = a;
     }
 }
