@@ -74,6 +74,19 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 }
 
 // KS: 1 | 2 | 3 (the tap loop is unrolled); nearest x2 upsampling never reaches the kernel (launch_conv_up2)
+// kernel-side view of the parameters for this block's sub-pixel phase (ConvParams::phases)
+__device__ __forceinline__ ConvParams phase_params(const ConvParams &in, int ph) {
+    ConvParams p = in;
+    if (in.phases > 1) {
+        p.org_y = p.out_oy = ph >> 1;
+        p.org_x = p.out_ox = ph & 1;
+        p.w = in.w + (size_t)ph * in.phase_w_stride;
+        p.stats_slice0 = in.stats_slice0 + ph * in.phase_slices;
+        if (in.part) p.part = in.part + (size_t)ph * in.phase_part_stride;
+    }
+    return p;
+}
+
 // residual element o (= pixel * C + channel) of a tensor stored in the split-f16 format: hi + lo
 __device__ __forceinline__ float load_split(const float *base, unsigned o) {
     const _Float16 *hp = reinterpret_cast<const _Float16 *>(base + (o & ~31u)) + (o & 31u);
@@ -264,7 +277,8 @@ __device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const f
 // NS: LDS pipeline stages (power of two or 3); the DMA of tile k+NS-1 is issued while tile k is
 // multiplied, so NS-2 tiles stay in flight across a barrier (counted vmcnt + raw s_barrier)
 template <int BM, int BN, int WGM, int WGN, int KS, int PREC, int NS>
-__global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p) {
+__global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p_in) {
+    const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -548,7 +562,8 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // MS: MFMA shape of the consumers, 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16: same
 // FLOP per cycle, but the chip holds a higher clock on it under load — MI355X_MICROARCH.md, DVFS (7))
 template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
-__global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p) {
+__global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in) {
+    const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -882,7 +897,7 @@ void launch_halo(const ConvParams &p, hipStream_t s) {
         attr_set = true;
     }
     const int M = p.B * p.Hout * p.Wout;
-    hipLaunchKernelGGL(kern, dim3((M / BM) * ((p.out.C + BN - 1) / BN)), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((M / BM) * ((p.out.C + BN - 1) / BN), 1, p.phases), dim3(512), lds, s, p);
 }
 
 // consumer MFMA shape of the halo kernels: 16x16x32 with the four consumer waves stacked along M
@@ -917,7 +932,7 @@ void launch_inst2(const ConvParams &p, hipStream_t s) {
     }
     const int M = p.B * p.Hout * p.Wout;
     const int tilesM = (M + BM - 1) / BM, tilesN = (p.out.C + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN, p.splits > 1 ? p.splits : 1), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN, p.splits > 1 ? p.splits : 1, p.phases), dim3(512), lds, s, p);
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int PREC>
@@ -948,7 +963,8 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
 // zero-bordered (pad 1), up2 only with ks 3 / stride 1 / single input, every tensor < 4 GiB
 // (32-bit byte offsets in the DMA addressing).
 // split-K second pass: out = sum_s part[s] + bias + FeatureWiseAffine bias + residual
-__global__ void conv_splitk_reduce_kernel(const ConvParams p, int M, int HWo) {
+__global__ void conv_splitk_reduce_kernel(const ConvParams p_in, int M, int HWo) {
+    const ConvParams p = phase_params(p_in, blockIdx.y);
     const int Cout = p.out.C, C4 = Cout >> 2;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * C4) return;
@@ -1031,7 +1047,7 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     }
     if (p.splits > 1) {
         const size_t items = (size_t)M * (p.out.C >> 2);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p,
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256), p.phases), dim3(256), 0, s, p,
                            (int)M, p.Hout * p.Wout);
     }
 }
@@ -1040,19 +1056,16 @@ void launch_conv_up2(const ConvParams &p_in, hipStream_t s) {
     const int H = p_in.Hout / 2, W = p_in.Wout / 2, Cout = p_in.out.C;
     const int Cin = p_in.in0.C + (p_in.in1.p ? p_in.in1.C : 0);
     const long Ml = (long)p_in.B * H * W;
-    const int per_phase = (H * W) / conv_tile_m(Ml, Cout);
-    for (int ph = 0; ph < 4; ++ph) {
-        ConvParams p = p_in;
-        p.ks = 2; p.stride = 1; p.up2 = 0;
-        p.Hout = H; p.Wout = W;
-        p.org_y = p.out_oy = ph >> 1;
-        p.org_x = p.out_ox = ph & 1;
-        p.out_step = 2;
-        p.w = p_in.w + (size_t)ph * 4 * Cout * Cin;
-        p.stats_slice0 = ph * per_phase;
-        p.splits = p.part ? conv_splits(Ml, Cout, Cin) : 1;
-        launch_conv(p, s);
-    }
+    ConvParams p = p_in;            // the four phases are one launch: blockIdx.z picks (py, px)
+    p.ks = 2; p.stride = 1; p.up2 = 0;
+    p.Hout = H; p.Wout = W;
+    p.out_step = 2;
+    p.phases = 4;
+    p.phase_w_stride = (size_t)4 * Cout * Cin;
+    p.phase_slices = (H * W) / conv_tile_m(Ml, Cout);
+    p.splits = p.part ? conv_splits(Ml, Cout, Cin) : 1;
+    p.phase_part_stride = p.splits > 1 ? (size_t)p.splits * Ml * Cout : 0;
+    launch_conv(p, s);
 }
 
 void make_up2_phase_weights(const float *w9, int Cout, int CinPad, float *dst) {

@@ -460,7 +460,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             } else if (m.kind == M_UP) {
                 const long Ml = Mo / 4;                       // each sub-pixel phase is a conv over the low-res pixels
                 const int sp = conv_splits(Ml, oc, m.conv.cin_pad);
-                if (sp > 1) max_part = std::max<uint64_t>(max_part, (uint64_t)sp * Ml * oc);
+                if (sp > 1) max_part = std::max<uint64_t>(max_part, (uint64_t)4 * sp * Ml * oc);   // 4 phases in one launch
             } else {
                 want(oc, m.conv.cin_pad);
             }

@@ -34,6 +34,11 @@ struct ConvParams {
     int org_y = 0, org_x = 0;
     int out_step = 1, out_oy = 0, out_ox = 0;
     int stats_slice0 = 0;              // first statistics slice of this launch
+    // phases > 1 (= 4): one launch runs the four sub-pixel phases of an upsample conv on blockIdx.z
+    // (grid.y of the split-K reduce): phase ph = (py, px) sets org_* = out_o* = (py, px) and advances
+    // w by ph * phase_w_stride floats, stats_slice0 by ph * phase_slices, part by ph * phase_part_stride
+    int phases = 1, phase_slices = 0;
+    size_t phase_w_stride = 0, phase_part_stride = 0;
     const float *w = nullptr;          // packed [ks*ks][Cout][Cin]
     // optional fused 1x1 term (ResnetBlock.res_conv, unet.py:102-103,110): out += in2 (*) w2, read at
     // the output pixel; same precision format and (for prec 1) the same weight scale as w
