@@ -74,6 +74,10 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
 }
 
 // KS: 1 | 2 | 3 (the tap loop is unrolled); nearest x2 upsampling never reaches the kernel (launch_conv_up2)
+// m / (Hout*Wout) and rem / Wout of the tile address set-up: shifts when the sizes are powers of two
+__device__ __forceinline__ int div_hw(const ConvParams &p, int m, int HWo) { return p.hw_shift >= 0 ? (m >> p.hw_shift) : m / HWo; }
+__device__ __forceinline__ int div_w(const ConvParams &p, int rem, int W) { return p.w_shift >= 0 ? (rem >> p.w_shift) : rem / W; }
+
 // kernel-side view of the parameters for this block's sub-pixel phase (ConvParams::phases)
 __device__ __forceinline__ ConvParams phase_params(const ConvParams &in, int ph) {
     ConvParams p = in;
@@ -327,9 +331,9 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         // epilogue tables: one row per thread (clamped rows are never stored)
         if (tid < BM) {
             const int m = min(m0 + tid, M - 1);
-            const int n = m / HWo;
+            const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
-            const int oy = rem / p.Wout;
+            const int oy = div_w(p, rem, p.Wout);
             rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox);
             rowimg[tid] = n;
         }
@@ -348,9 +352,9 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
-            const int n = m / HWo;
+            const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
-            const int oy = rem / p.Wout;
+            const int oy = div_w(p, rem, p.Wout);
             const int ox = rem - oy * p.Wout;
             const unsigned pixbase = (unsigned)((n * Hp + oy * p.stride - cpad + tpad + p.org_y) * Wp +
                                                 ox * p.stride - cpad + tpad + p.org_x);
@@ -367,9 +371,9 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
-            const int n = m / HWo;
+            const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
-            const int oy = rem / p.Wout;
+            const int oy = div_w(p, rem, p.Wout);
             vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)C2a * 4u + schunk16 : 0u;
             vA2b[i] = C2 > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * p.Wout) * (unsigned)(C2t - C2a) * 4u + schunk16 : 0u;
         });
@@ -611,9 +615,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in)
         const int tid = threadIdx.x - 256;
         if (tid < BM) {
             const int m = min(m0 + tid, M - 1);
-            const int n = m / HWo;
+            const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
-            const int oy = rem / W;
+            const int oy = div_w(p, rem, W);
             rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
             rowimg[tid] = n;
         }
@@ -628,9 +632,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in)
             int sg = R / SEGP, jx = R - sg * SEGP;
             if (sg >= nseg) { sg = nseg - 1; jx = 0; }              // unused tail rows: any valid pixel
             const int m = m0 + sg * SEG;
-            const int n = m / HWo;
+            const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
-            const int y = rem / W, x0 = rem - y * W;
+            const int y = div_w(p, rem, W), x0 = rem - y * W;
             // KS 3: padded coordinates of (y - 1 + dy, x0 - 1 + jx) are (y + dy, x0 + jx); KS 2: the phase's
             // window starts at padded (y + org_y, x0 + org_x); dy is added per group
             const unsigned pix = (unsigned)((n * Hp + y + p.org_y) * Wp + x0 + jx + p.org_x);
@@ -647,9 +651,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in)
         static_for<AR>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
-            const int n = m / HWo;
+            const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
-            const int oy = rem / W;
+            const int oy = div_w(p, rem, W);
             vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * W) * (unsigned)C2a * 4u + schunk16 : 0u;
             vA2b[i] = C2 > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * W) * (unsigned)(C2 - C2a) * 4u + schunk16 : 0u;
         });
@@ -1025,6 +1029,11 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     ConvParams p = p_in;
     if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
     const long M = (long)p.B * p.Hout * p.Wout;
+    {
+        auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+        p.hw_shift = lg(p.Hout * p.Wout);
+        p.w_shift = lg(p.Wout);
+    }
     if (p.part == nullptr) p.splits = 1;
     if (p.splits > 1) p.stats = nullptr;   // the caller falls back to the statistics kernel
     switch (conv_tile_choice(M, p.out.C)) {

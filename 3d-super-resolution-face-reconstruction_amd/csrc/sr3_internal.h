@@ -34,6 +34,9 @@ struct ConvParams {
     int org_y = 0, org_x = 0;
     int out_step = 1, out_oy = 0, out_ox = 0;
     int stats_slice0 = 0;              // first statistics slice of this launch
+    // log2(Hout*Wout) / log2(Wout) when they are powers of two (set by launch_conv, -1 otherwise): the
+    // per-lane address set-up of a tile then uses shifts instead of integer divisions
+    int hw_shift = -1, w_shift = -1;
     // phases > 1 (= 4): one launch runs the four sub-pixel phases of an upsample conv on blockIdx.z
     // (grid.y of the split-K reduce): phase ph = (py, px) sets org_* = out_o* = (py, px) and advances
     // w by ph * phase_w_stride floats, stats_slice0 by ph * phase_slices, part by ph * phase_part_stride
