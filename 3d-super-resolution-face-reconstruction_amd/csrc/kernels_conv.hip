@@ -196,21 +196,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 template <int BM, int BN, int WGM, int WGN, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc)[MT][NT], float *smem,
                                                 const int *rowpix, const int *rowimg, int m0, int n0, int M, int wm,
-                                                int wn, int l16, int q) {
+                                                int wn, int l16, int q, const float *colbias) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     const int Cout = p.out.C;
-    const int img0 = rowimg[wm * WM];
-    const bool one_img = img0 == rowimg[wm * WM + WM - 1];      // rows are consecutive pixels: first == last image
+    // colbias[BN] (LDS, staged by the producers at kernel start so that no global load sits on the
+    // epilogue's critical path): bias + FeatureWiseAffine bias when the whole tile lies in one image
+    // (flag in colbias[BN]); otherwise bias only and the per-image part is gathered per row
+    const bool one_img = reinterpret_cast<const int *>(colbias)[BN] != 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + wn * WN + nt * 16 + l16;
         const int nc = min(n, Cout - 1);
-        float bs = p.bias ? p.bias[nc] : 0.f;
-        // FeatureWiseAffine bias: one value per (image, channel). When all rows of this wave's tile
-        // belong to one image (every level but the 8x8 one) it joins the column bias; otherwise it
-        // is gathered per row.
+        const float bs = colbias[wn * WN + nt * 16 + l16];
         const bool cb_rows = p.chan_bias != nullptr && !one_img;
-        if (p.chan_bias != nullptr && one_img) bs += p.chan_bias[(size_t)img0 * p.chan_bias_stride + nc];
         double st1 = 0.0, st2 = 0.0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -583,6 +581,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in)
     float *Bring = smem + 2 * ASTG;         // [2][BN][32]
     int *rowpix = reinterpret_cast<int *>(smem + 2 * ASTG + 2 * BSTG);
     int *rowimg = rowpix + BM;
+    float *colbias = reinterpret_cast<float *>(rowimg + BM);    // [BN] + 1 flag word (conv_epilogue16)
 
     const int C0 = p.in0.C, C1 = p.in1.p ? p.in1.C : 0;
     const int Cin = C0 + C1;
@@ -620,6 +619,17 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in)
             const int oy = div_w(p, rem, W);
             rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
             rowimg[tid] = n;
+        }
+        if constexpr (MS == 16) {           // column bias of the epilogue, fetched now, read from LDS later
+            const int img_a = div_hw(p, m0, HWo), img_b = div_hw(p, min(m0 + BM - 1, M - 1), HWo);
+            const bool one = img_a == img_b;
+            if (tid < BN) {
+                const int nc = min(n0 + tid, Cout - 1);
+                float v = p.bias ? p.bias[nc] : 0.f;
+                if (p.chan_bias != nullptr && one) v += p.chan_bias[(size_t)img_a * p.chan_bias_stride + nc];
+                colbias[tid] = v;
+            }
+            if (tid == 0) reinterpret_cast<int *>(colbias)[BN] = one ? 1 : 0;
         }
         const int rsub = lane >> 3;
         const unsigned schunk16 = (unsigned)(((lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7)) * 16);
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in)
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] *= p.w_unscale;
-        conv_epilogue16<BM, BN, WGM, WGN, MT, NT>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, l16, q);
+        conv_epilogue16<BM, BN, WGM, WGN, MT, NT>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, l16, q, colbias);
         return;
     }
     const int li = lane & 31, lh = lane >> 5;
@@ -893,7 +903,7 @@ template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
 void launch_halo(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr int RA = (BM + (KS - 1) * (BM / SEGMIN) + 7) / 8 * 8;
-    constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM) * sizeof(float);
+    constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM + BN + 4) * sizeof(float);
     auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
