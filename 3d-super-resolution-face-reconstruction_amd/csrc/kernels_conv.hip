@@ -192,69 +192,133 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 }
 
 // Epilogue for 16x16 accumulator tiles (v_mfma_f32_16x16x32_f16): C/D map col = lane & 15,
-// row = 4 * (lane >> 4) + r. Same duties as conv_epilogue (no split-K: the halo kernels never split).
+// row = 4 * (lane >> 4) + r. Same duties as conv_epilogue (no split-K: the halo kernels never split;
+// they also guarantee M % BM == 0 and Cout % BN == 0, so nothing is masked).
+// Written as a sequence of whole-tile phases, each behind ONE test of its (uniform) option — values
+// stay in the accumulator registers in between — instead of testing every option per element: the
+// per-element form compiled to ~140 branches with a wait for its loads in every basic block and cost a
+// 128x64 tile as much as a third of its K loop.
+// colbias[BN] (LDS, staged by the producers at kernel start so that no global load sits on the
+// epilogue's critical path): bias + FeatureWiseAffine bias when the whole tile lies in one image
+// (flag in colbias[BN]); otherwise bias only and the per-image part is gathered per row.
 template <int BM, int BN, int WGM, int WGN, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc)[MT][NT], float *smem,
                                                 const int *rowpix, const int *rowimg, int m0, int n0, int M, int wm,
                                                 int wn, int l16, int q, const float *colbias) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
-    const int Cout = p.out.C;
-    // colbias[BN] (LDS, staged by the producers at kernel start so that no global load sits on the
-    // epilogue's critical path): bias + FeatureWiseAffine bias when the whole tile lies in one image
-    // (flag in colbias[BN]); otherwise bias only and the per-image part is gathered per row
+    const unsigned Cout = (unsigned)p.out.C;
     const bool one_img = reinterpret_cast<const int *>(colbias)[BN] != 0;
+    const unsigned ncol = (unsigned)(n0 + wn * WN + l16);       // column of nt = 0; + 16 per nt
+    // element offset of (row, column 0) for this lane's 4 rows of every row tile
+    unsigned rb[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int4 rp = *reinterpret_cast<const int4 *>(rowpix + wm * WM + mt * 16 + 4 * q);
+        rb[mt][0] = (unsigned)rp.x * Cout; rb[mt][1] = (unsigned)rp.y * Cout;
+        rb[mt][2] = (unsigned)rp.z * Cout; rb[mt][3] = (unsigned)rp.w * Cout;
+    }
+    // 1. column bias
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * WN + nt * 16 + l16;
-        const int nc = min(n, Cout - 1);
         const float bs = colbias[wn * WN + nt * 16 + l16];
-        const bool cb_rows = p.chan_bias != nullptr && !one_img;
-        double st1 = 0.0, st2 = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][nt][j] += bs;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. FeatureWiseAffine bias per row (tiles that span two images: the 8x8 level)
+    if (p.chan_bias != nullptr && !one_img) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int rbase = wm * WM + mt * 16 + 4 * q;
-            float add[4];
-            unsigned o[4];
+            const int4 ri = *reinterpret_cast<const int4 *>(rowimg + wm * WM + mt * 16 + 4 * q);
+            const int im[4] = {ri.x, ri.y, ri.z, ri.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                add[j] = bs;
-                o[j] = (unsigned)rowpix[rbase + j] * (unsigned)Cout + (unsigned)nc;
-            }
-            if (p.resid.p != nullptr) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) add[j] += p.resid_split ? load_split(p.resid.p, o[j]) : p.resid.p[o[j]];
-            }
-            if (cb_rows) {
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    add[j] += p.chan_bias[(size_t)rowimg[rbase + j] * p.chan_bias_stride + nc];
+                    acc[mt][nt][j] += p.chan_bias[(size_t)im[j] * p.chan_bias_stride + ncol + nt * 16];
+                __builtin_amdgcn_sched_barrier(0);      // 4 loads in flight at a time: bounds the registers
             }
+        }
+    }
+    // 3. residual (fp32 tensor, or hi + lo of a split-only tensor)
+    if (p.resid.p != nullptr) {
+        if (p.resid_split) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + rbase + j;
-                const float v = acc[mt][nt][j] + add[j];
-                if (m < M && n < Cout && p.out_f32) p.out.p[o[j]] = v;
-                if (p.out_split.p != nullptr) {     // split-f16 twin, see conv_epilogue_impl
-                    const float g = fminf(fmaxf(v, -65504.0f), 65504.0f);
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][nt][j] += load_split(p.resid.p, rb[mt][j] + ncol + nt * 16);
+                __builtin_amdgcn_sched_barrier(0);      // one column of tiles in flight at a time
+            }
+        } else {
+            const char *rbase = reinterpret_cast<const char *>(p.resid.p);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mt][nt][j] += *reinterpret_cast<const float *>(rbase + (rb[mt][j] + ncol + nt * 16) * 4u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // 4. fp32 output (32-bit byte offsets: every tensor is < 4 GiB)
+    if (p.out_f32) {
+        char *obase = reinterpret_cast<char *>(p.out.p);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float *>(obase + (rb[mt][j] + ncol + nt * 16) * 4u) = acc[mt][nt][j];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // 5. split-f16 twin: per 32-channel chunk 32 hi halfs | 32 lo halfs. Lanes l16, l16 ^ 1 hold
+    //    neighbouring channels: the even lane stores both hi halfs, the odd lane both lo halfs.
+    if (p.out_split.p != nullptr) {
+        char *tbase = reinterpret_cast<char *>(p.out_split.p);
+        const bool odd = l16 & 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g = fminf(fmaxf(acc[mt][nt][j], -65504.0f), 65504.0f);
                     const _Float16 hi = (_Float16)g;
                     const _Float16 lo = (_Float16)(g - (float)hi);
                     const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) |
                                          ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
-                    const bool odd = l16 & 1;
+                    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
                     const unsigned word = odd ? ((oth >> 16) | (own & 0xFFFF0000u)) : ((own & 0xFFFFu) | (oth << 16));
-                    if (m < M && n < Cout) {
-                        unsigned *hd = reinterpret_cast<unsigned *>(p.out_split.p + (o[j] & ~31u));
-                        hd[(odd ? 16 : 0) + ((o[j] & 31u) >> 1)] = word;
-                    }
+                    const unsigned o = rb[mt][j] + ncol + nt * 16;
+                    // chunk base (o & ~31) floats = 128 B; word index (odd ? 16 : 0) + (o & 31) / 2
+                    *reinterpret_cast<unsigned *>(tbase + ((o & ~31u) + (odd ? 16u : 0u) + ((o & 31u) >> 1)) * 4u) = word;
+                    if (j == 3) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (p.stats != nullptr) { st1 += (double)v; st2 = fma((double)v, (double)v, st2); }
-            }
-        }
-        if (p.stats != nullptr)
-            reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
     }
-    if (p.stats != nullptr) __syncthreads();
+    // 6. fused GroupNorm statistics of the stored values: fp64 column sums, handed to the producers
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double st1 = 0.0, st2 = 0.0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = (double)acc[mt][nt][j];
+                    st1 += v; st2 = fma(v, v, st2);
+                }
+            reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
 }
 
 // Producer side of the fused statistics: after the consumers' sums are in LDS, the producer
@@ -564,7 +628,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // MS: MFMA shape of the consumers, 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16: same
 // FLOP per cycle, but the chip holds a higher clock on it under load — MI355X_MICROARCH.md, DVFS (7))
 template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
-__global__ __launch_bounds__(512, 4) void conv3x3_halo_h3(const ConvParams p_in) {
+__global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_halo_h3(const ConvParams p_in) {
     const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -923,7 +987,7 @@ static bool halo_mfma16() {
 }
 
 // preconditions of the x-halo kernel for tile height BM
-static bool halo_ok(const ConvParams &p, int BM, int segmin) {
+static bool halo_ok(const ConvParams &p, int BM, int segmin, int bn) {
     static const int off = getenv("SR3_NO_HALO") ? atoi(getenv("SR3_NO_HALO")) : 0;
     if (off || p.prec != 1 || (p.ks != 3 && p.ks != 2) || p.stride != 1 || p.up2 || p.splits > 1 || p.in0.pad != 1) return false;
     const int W = p.Wout;
@@ -931,7 +995,8 @@ static bool halo_ok(const ConvParams &p, int BM, int segmin) {
     const int seg = W < BM ? W : BM;
     if (seg < segmin || (W % seg) || (BM % seg)) return false;
     const long M = (long)p.B * p.Hout * W;
-    return (M % BM) == 0 && (!p.in2.p || (p.in2.C % 32) == 0) && (!p.in2b.p || (p.in2b.C % 32) == 0);
+    // no masking anywhere in the halo kernels: whole tiles in M and (for the tile width bn the caller picks) in N
+    return (M % BM) == 0 && (p.out.C % bn) == 0 && (!p.in2.p || (p.in2.C % 32) == 0) && (!p.in2b.p || (p.in2b.C % 32) == 0);
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, int PREC, int NS>
@@ -1049,7 +1114,7 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
-        if (halo_ok(p, 128, 32)) {
+        if (halo_ok(p, 128, 32, 64)) {
             if (halo_mfma16()) { if (p.ks == 3) launch_halo<128, 64, 4, 1, 32, 3, 16>(p, s); else launch_halo<128, 64, 4, 1, 32, 2, 16>(p, s); }
             else { if (p.ks == 3) launch_halo<128, 64, 2, 2, 32, 3, 32>(p, s); else launch_halo<128, 64, 2, 2, 32, 2, 32>(p, s); }
         }
@@ -1057,7 +1122,7 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         break;
     case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
     default:
-        if (halo_ok(p, 128, 8)) {
+        if (halo_ok(p, 128, 8, 128)) {
             if (halo_mfma16()) { if (p.ks == 3) launch_halo<128, 128, 4, 1, 8, 3, 16>(p, s); else launch_halo<128, 128, 4, 1, 8, 2, 16>(p, s); }
             else { if (p.ks == 3) launch_halo<128, 128, 2, 2, 8, 3, 32>(p, s); else launch_halo<128, 128, 2, 2, 8, 2, 32>(p, s); }
         }
