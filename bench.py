@@ -30,6 +30,10 @@ import time
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: RCCL (and any cross-process CUDA-tensor
+# sharing) needs this before the HSA runtime starts; already exported on the benchmark boxes
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = "3d-super-resolution-face-reconstruction_amd"
 sys.path.insert(0, ROOT)
