@@ -120,7 +120,12 @@ def main():
     schedule = importlib.import_module(PKG + ".schedule")
     Engine = importlib.import_module(PKG + ".engine").Engine
 
-    rank, world, local = distm.init_from_env("nccl")
+    # RCCL over xGMI in production; SR3_DIST_BACKEND=gloo rehearses the N > 1 control flow (barriers,
+    # max-over-ranks timing, gather, rank-0 report) where fewer GPUs than ranks exist
+    backend = os.environ.get("SR3_DIST_BACKEND", "nccl")
+    rank, world, local = distm.init_from_env(backend)
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -164,11 +169,14 @@ def main():
     t_next = run_steps(K, t_next)
     eng.sample_end(out.data_ptr())
     if world > 1:
-        dist.all_gather_into_tensor(gathered, out)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, out)
+        else:
+            gathered = distm.all_gather_images(out.cpu(), B * world)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     sec_per_step = dt / K
