@@ -61,6 +61,7 @@ PROTOTYPES = {
     "sr3_sample_begin": (_I, [_P, _F, _I, _I, _I, _F, _U64, _U64]),
     "sr3_sample_step": (_I, [_P, _I, _F]),
     "sr3_sample_end": (_I, [_P, _F]),
+    "sr3_range_check": (_I, [_P]),
     "sr3_philox_normal": (_I, [_P, _U64, _U64, C.c_uint32, _I, _F]),
     "sr3_profile_enable": (_I, [_P, _I]),
     "sr3_profile_reset": (_I, [_P]),

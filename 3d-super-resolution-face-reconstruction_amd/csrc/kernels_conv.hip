@@ -45,6 +45,14 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
+// timing experiments (tools/conv_bench.py) exist only in builds with -DSR3_EXPERIMENTS: the product
+// library ignores SR3_CONV_DBG and carries no experiment branches in its kernels
+#ifdef SR3_EXPERIMENTS
+#define SR3_DBG(p) ((p).dbg)
+#else
+#define SR3_DBG(p) 0
+#endif
+
 constexpr int BK = 32;            // channels per K-step
 constexpr int ROWF = 32;          // floats per LDS row (128 B, unpadded)
 
@@ -124,6 +132,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
         return;
     }
     // processed 4 accumulator registers (4 consecutive rows) at a time to keep registers low
+    float split_absmax = 0.f;          // largest |value| stored in the split-f16 format (range check)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * WN + ni * 32 + li;
@@ -160,7 +169,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
                         // twin in the conv input format: per 32-channel chunk 32 hi halfs | 32 lo halfs.
                         // Lanes li, li^1 hold neighbouring channels: the even lane stores both hi halfs,
                         // the odd lane both lo halfs (one 4-byte store per lane instead of two 2-byte ones).
-                        const float g = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                        // no clamp: a value beyond the fp16 range is DETECTED (split_absmax -> ConvParams::ovf,
+                        // the API call then fails) instead of being silently saturated
+                        const float g = v;
+                        split_absmax = fmaxf(split_absmax, fabsf(g));
                         const _Float16 hi = (_Float16)g;
                         const _Float16 lo = (_Float16)(g - (float)hi);
                         const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) |
@@ -181,6 +193,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
         if (p.stats != nullptr)
             reinterpret_cast<double2 *>(smem)[(wm * 2 + lh) * BN + wn * WN + ni * 32 + li] = make_double2(st1, st2);
     }
+    if (p.ovf != nullptr && split_absmax > SPLIT_F16_MAX) *p.ovf = 1;
     if (p.stats != nullptr) __syncthreads();
 }
 
@@ -283,13 +296,15 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
     if (p.out_split.p != nullptr) {
         char *tbase = reinterpret_cast<char *>(p.out_split.p);
         const bool odd = l16 & 1;
+        float split_absmax = 0.f;      // range check instead of a silent clamp (ConvParams::ovf)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g = fminf(fmaxf(acc[mt][nt][j], -65504.0f), 65504.0f);
+                    const float g = acc[mt][nt][j];
+                    split_absmax = fmaxf(split_absmax, fabsf(g));
                     const _Float16 hi = (_Float16)g;
                     const _Float16 lo = (_Float16)(g - (float)hi);
                     const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) |
@@ -301,6 +316,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
                     *reinterpret_cast<unsigned *>(tbase + ((o & ~31u) + (odd ? 16u : 0u) + ((o & 31u) >> 1)) * 4u) = word;
                     if (j == 3) __builtin_amdgcn_sched_barrier(0);
                 }
+        if (p.ovf != nullptr && split_absmax > SPLIT_F16_MAX) *p.ovf = 1;
     }
     // 6. fused GroupNorm statistics of the stored values: fp64 column sums, handed to the producers
     if (p.stats != nullptr) {
@@ -455,15 +471,15 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                 constexpr int dy = tap / KS, dx = tap % KS;
                 float *Ad = smem + (k % NS) * STAGE + w * 256;
                 float *Bd = Ad + BM * ROWF;
-                if (!(p.dbg & 1) || k == 0) {
+                if (!(SR3_DBG(p) & 1) || k == 0) {
                     const char *ab = abase + (size_t)(dy * Wp + dx) * Cs * 4;
-                    if (p.dbg & 2) ab = reinterpret_cast<const char *>(p.in0.p);   // experiment: cache-hot source
+                    if (SR3_DBG(p) & 2) ab = reinterpret_cast<const char *>(p.in0.p);   // experiment: cache-hot source
                     static_for<AR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         const unsigned vo = first ? vA0[i] : vA1[i];
                         dma16(reinterpret_cast<const float *>(ab + vo), Ad + i * 1024);
                     });
-                    const char *wb = (p.dbg & 2) ? reinterpret_cast<const char *>(p.w) : wbase + (size_t)tap * tapstride * 4;
+                    const char *wb = (SR3_DBG(p) & 2) ? reinterpret_cast<const char *>(p.w) : wbase + (size_t)tap * tapstride * 4;
                     static_for<BR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
@@ -1063,7 +1079,8 @@ __global__ void conv_splitk_reduce_kernel(const ConvParams p_in, int M, int HWo)
         if (p.resid.p) v[j] += p.resid_split ? load_split(p.resid.p, (unsigned)(o + j)) : p.resid.p[o + j];
         if (p.out_f32) p.out.p[o + j] = v[j];
         if (p.out_split.p != nullptr) {
-            const float g = fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+            const float g = v[j];
+            if (p.ovf != nullptr && fabsf(g) > SPLIT_F16_MAX) *p.ovf = 1;     // detected, not clamped
             const _Float16 hi = (_Float16)g;
             _Float16 *hd = reinterpret_cast<_Float16 *>(p.out_split.p + ((o + j) & ~(size_t)31)) + ((o + j) & 31);
             hd[0] = hi;
@@ -1102,7 +1119,9 @@ int conv_splits(long M, int Cout, int Cin) {
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     if (p_in.up2) { launch_conv_up2(p_in, s); return; }     // weights must be in phase form (make_up2_phase_weights)
     ConvParams p = p_in;
+#ifdef SR3_EXPERIMENTS
     if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
+#endif
     const long M = (long)p.B * p.Hout * p.Wout;
     {
         auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };

@@ -180,14 +180,15 @@ __device__ __forceinline__ float swish_fast(float x) {
 }
 
 template <int SPLIT>
-__device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8]) {
+__device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8], float &absmax) {
     if (SPLIT) {
-        // chunk of 32 channels = 128 B: halfs [0,32) hi, [32,64) lo; x = hi + lo to ~2^-22 |x|
-        const float lim = 65504.0f;
+        // chunk of 32 channels = 128 B: halfs [0,32) hi, [32,64) lo; x = hi + lo to ~2^-22 |x|.
+        // Values beyond the fp16 range are not clamped but detected (absmax -> the ovf flag).
         h16x8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float g = fminf(fmaxf(f[j], -lim), lim);
+            const float g = f[j];
+            absmax = fmaxf(absmax, fabsf(g));
             hi[j] = (_Float16)g;
             lo[j] = (_Float16)(g - (float)hi[j]);
         }
@@ -204,7 +205,7 @@ template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, const TDesc out,
-                                                       const TDesc raw, const int in_split) {
+                                                       const TDesc raw, const int in_split, int *ovf) {
     // a thread owns 8 consecutive channels of one pixel (two 16-B loads, 16-B stores);
     // grid: x = chunks of (pixel-in-row, channel octet), y = n * H + row
     const int C0 = in0.C, C = out.C, C8 = C >> 3;
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
         const float4 v1 = *reinterpret_cast<const float4 *>(pixp + cl + 4);
         f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
     }
-    if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f);
+    float absmax = 0.f;
+    if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f, absmax);
     if (MODE != 0) {
         const float *scp = scale + (size_t)n * C + c, *shp = shift + (size_t)n * C + c;
         const float4 s0 = *reinterpret_cast<const float4 *>(scp), s1 = *reinterpret_cast<const float4 *>(scp + 4);
@@ -243,16 +245,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
     }
-    store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f);
+    store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
+    if (SPLIT && ovf != nullptr && absmax > SPLIT_F16_MAX) *ovf = 1;
 }
 
 } // namespace
 
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
-                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw, int in_split) {
+                     int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw, int in_split, int *ovf) {
     const int items = out.W * (out.C >> 3);
     const dim3 grid((items + 255) / 256, B * out.H);
-#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split)
+#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf)
     if (split) {
         if (mode == 0) SR3_GA(0, 1); else if (mode == 1) SR3_GA(1, 1); else SR3_GA(2, 1);
     } else {

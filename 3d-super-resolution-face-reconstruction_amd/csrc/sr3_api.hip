@@ -121,6 +121,9 @@ struct sr3_ctx {
     bool fused_dirty = true;   // fused bias / common weight scales need (re)building
     bool no_fused_stats = false;   // SR3_NO_FUSED_STATS=1: always run the statistics kernel (A/B testing)
     bool all_fused = false;        // every GroupNorm of the current workspace gets its statistics from a conv epilogue
+    // split-f16 range check: kernels set *d_ovf when a value stored in the split format exceeds the
+    // fp16 range (|v| > 65504); sr3_unet_forward / sr3_sample_end / sr3_range_check read it and fail
+    int *d_ovf = nullptr, *h_ovf = nullptr;
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -231,6 +234,9 @@ GNRef add_gn(sr3_ctx *c, const std::string &prefix, int C) {
     return g;
 }
 
+// identity skip as extra K-steps of conv2 (ResBlock::ident_w): narrow blocks that keep their width
+bool ident_eligible(const ResBlock &rb) { return !rb.has_res && rb.cout <= 128 && (rb.cout % 32) == 0; }
+
 Module make_res(sr3_ctx *c, const std::string &prefix, int cin, int cout, bool attn) {
     Module m;
     m.kind = M_RES;
@@ -253,6 +259,8 @@ Module make_res(sr3_ctx *c, const std::string &prefix, int cin, int cout, bool a
     if (rb.has_res) {
         rb.res = add_conv(c, rp + ".res_conv", cin, cout, 1, true);
         for (int idx : {rb.c2.w, rb.c2.b, rb.res.w, rb.res.b}) c->params[idx].keep_host = true;
+    } else if (ident_eligible(rb)) {
+        c->params[rb.c2.w].keep_host = true;     // prepare_fused may re-split conv2 with a capped scale
     }
     if (attn) {
         rb.agn = add_gn(c, prefix + ".attn.norm", cout);
@@ -582,7 +590,7 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
     else
         launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
                                 c->gpart, c->gscale, c->gshift, c->stream);
-    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split);
+    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split, c->d_ovf);
     c->pend();
 }
 
@@ -607,6 +615,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
     p.splits = conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
     p.part = c->part;
+    p.ovf = c->d_ovf;
     if (cv2) {
         p.in2 = in2; p.in2b = in2b;
         p.w2 = p.prec ? c->params[cv2->w].dev_split : c->params[cv2->w].dev;
@@ -692,7 +701,7 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
             if (c->prec) {      // the 6 (of 32 padded) input channels in split-f16 form: the first conv then runs
                                 // on the fast path too instead of 9 mostly-zero K-steps of f32 MFMA
                 c->pbegin(F_GN);
-                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream);
+                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream, TDesc(), 0, c->d_ovf);
                 c->pend();
                 run_conv(c, c->x0s, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s,
                          kNone, !(so_mode && m.out_s.p));
@@ -708,7 +717,7 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
                          kNone, !(so_mode && m.out_s.p));
             } else if (c->prec) {               // no twin: re-store the raw input in split-f16 form first
                 c->pbegin(F_GN);
-                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream);
+                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, m.up_in, c->stream, TDesc(), 0, c->d_ovf);
                 c->pend();
                 run_conv(c, m.up_in, kNone, m.conv, B, stride, up2, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s);
             } else {
@@ -760,12 +769,25 @@ int prepare_fused(sr3_ctx *c) {
     if (!c->fused_dirty) return 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     for (auto &m : c->mods) {
-        if (m.kind != M_RES || m.rb.has_res || m.rb.cout > 128 || (m.rb.cout % 32)) continue;
+        if (m.kind != M_RES || !ident_eligible(m.rb)) continue;
         ResBlock &rb = m.rb;
         const size_t n = (size_t)rb.cout * rb.cout;
         std::vector<float> buf(n, 0.f);
         _Float16 *h = reinterpret_cast<_Float16 *>(buf.data());
-        const float v = 1.0f / c->params[rb.c2.w].w_unscale;        // 2^k of conv2's split weights
+        // The identity matrix holds 2^k as an fp16 number, so k <= 15 (2^16 is +inf in fp16 and the extra
+        // K-steps would compute x * inf: NaN). conv2 tensors with max|w| < 2^-5 (k >= 16; e.g. PyTorch's
+        // default init of a 128 -> 128 conv, bound 1/sqrt(1152)) are re-split with k = 15: hi + lo then
+        // still carries the weight to 2^-24 absolute in scaled units (fp16 subnormal spacing), far below
+        // the 2^-22 relative accuracy of the format.
+        Param &w2 = c->params[rb.c2.w];
+        int k = split_scale_exponent(w2.host.data(), w2.host.size());
+        if (k > 15) {
+            k = 15;
+            std::vector<float> sp(w2.host.size());
+            w2.w_unscale = split_conv_weight_k(w2.host.data(), (size_t)9 * w2.cout, w2.cin_pad, k, sp.data());
+            HIP_OK(hipMemcpy(w2.dev_split, sp.data(), w2.dev_floats * sizeof(float), hipMemcpyHostToDevice));
+        }
+        const float v = 1.0f / w2.w_unscale;                        // 2^k of conv2's split weights (k <= 15)
         for (int o = 0; o < rb.cout; ++o) h[((size_t)o * rb.cout + (o & ~31)) * 2 + (o & 31)] = (_Float16)v;
         if (!rb.ident_w) HIP_OK(hipMalloc(&rb.ident_w, n * sizeof(float)));
         HIP_OK(hipMemcpy(rb.ident_w, buf.data(), n * sizeof(float), hipMemcpyHostToDevice));
@@ -789,6 +811,24 @@ int prepare_fused(sr3_ctx *c) {
     }
     c->fused_dirty = false;
     return 0;
+}
+
+// clears the range-check flag (stream-ordered; never inside a captured step)
+int range_reset(sr3_ctx *c) {
+    HIP_OK(hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream));
+    return 0;
+}
+
+// Synchronises the stream and fails if any kernel since the last reset stored a value beyond the
+// fp16 range in the split-f16 format (such a value would otherwise corrupt the residual stream
+// silently). The flag is cleared either way.
+int range_check(sr3_ctx *c, const char *what) {
+    HIP_OK(hipMemcpyAsync(c->h_ovf, c->d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (*c->h_ovf == 0) return 0;
+    HIP_OK(hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream));
+    return fail("%s: an activation exceeded the fp16 range (|v| > 65504) of the split-f16 format; the result is "
+                "invalid — run this model with the exact f32 arithmetic (sr3_set_precision(ctx, 0))", what);
 }
 
 int check_ready(sr3_ctx *c) {
@@ -900,6 +940,12 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
     if (alloc_weights(c)) { sr3_destroy(c); return -1; }
     if (hipStreamCreate(&c->own_stream) != hipSuccess) { sr3_destroy(c); return fail("hipStreamCreate failed"); }
     c->stream = c->own_stream;
+    if (hipMalloc(&c->d_ovf, sizeof(int)) != hipSuccess || hipMemset(c->d_ovf, 0, sizeof(int)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_ovf), sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        sr3_destroy(c);
+        return fail("allocating the range-check flag failed");
+    }
+    *c->h_ovf = 0;
     *out = c;
     return 0;
 }
@@ -921,6 +967,8 @@ void sr3_destroy(sr3_ctx *c) {
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_nl) (void)hipFree(c->d_nl);
     drop_graphs(c);
+    if (c->d_ovf) (void)hipFree(c->d_ovf);
+    if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     if (c->d_step) (void)hipFree(c->d_step);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1018,6 +1066,7 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     if (!x_dev || !noise_level_dev || !out_dev) return fail("sr3_unet_forward: null pointer");
     if (ensure_workspace(c, B, H, W)) return -1;
     c->sampling = false;
+    if (range_reset(c)) return -1;
     c->pbegin(F_MISC);
     launch_nchw_to_nhwc(x_dev, B, c->cfg.in_channel, c->x0, 0, c->stream);
     c->pend();
@@ -1027,7 +1076,7 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     launch_nhwc_to_nchw(c->eps, 0, B, c->cfg.out_channel, out_dev, c->stream);
     c->pend();
     HIP_OK(hipGetLastError());
-    return 0;
+    return c->prec ? range_check(c, "sr3_unet_forward") : 0;
 }
 
 int sr3_set_schedule(sr3_ctx *c, int T, const float *noise_level, const float *recip, const float *recipm1,
@@ -1069,6 +1118,7 @@ int sr3_sample_begin(sr3_ctx *c, const float *cond_dev, int B, int H, int W, con
     if (ensure_workspace(c, B, H, W)) return -1;
     c->seed = seed;
     c->image_offset = image_offset;
+    if (range_reset(c)) return -1;
     c->pbegin(F_MISC);
     if (cond_dev) launch_nchw_to_nhwc(cond_dev, B, nc, c->x0, 0, c->stream);
     launch_init_state(c->x0, nc, C, init_noise_dev, seed, image_offset, B, c->stream);
@@ -1094,7 +1144,14 @@ int sr3_sample_end(sr3_ctx *c, float *out_dev) {
     launch_nhwc_to_nchw(c->x0, c->cfg.in_channel - C, c->wB, C, out_dev, c->stream);
     c->pend();
     HIP_OK(hipGetLastError());
-    return 0;
+    // split-f16 mode: synchronises and fails if an activation left the fp16 range during the steps
+    return c->prec ? range_check(c, "sr3_sample_end") : 0;
+}
+
+int sr3_range_check(sr3_ctx *c) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    return range_check(c, "sr3_range_check");
 }
 
 int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const float *noise_dev, uint64_t seed,
@@ -1201,7 +1258,9 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     a.p = act;
     const TDesc i0 = unpadded(const_cast<float *>(in0_dev), C0, Hin, Win);
     const TDesc i1 = in1_dev ? unpadded(const_cast<float *>(in1_dev), C1, Hin, Win) : kNone;
-    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, c->prec, a, c->stream);
+    if (range_reset(c)) return -1;
+    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, c->prec, a, c->stream,
+                    TDesc(), 0, c->d_ovf);
     const int pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
     ConvParams p;
     p.in0 = a; p.B = B;
@@ -1218,7 +1277,7 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     HIP_OK(hipFree(act));
     if (db) HIP_OK(hipFree(db));
     HIP_OK(hipGetLastError());
-    return 0;
+    return c->prec ? range_check(c, "sr3_op_conv2d") : 0;
 }
 
 // Times `iters` launches of one conv shape on scratch buffers (random contents; f32 MFMA time does

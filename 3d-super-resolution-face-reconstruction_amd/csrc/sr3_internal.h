@@ -75,8 +75,13 @@ struct ConvParams {
     // adds the partials and applies the epilogue. splits <= 1: single pass.
     int splits = 1;
     float *part = nullptr;
+    // split-f16 range check: any value stored in the split format (out_split) with |v| > 65504 (or
+    // non-finite) sets *ovf = 1; the API call that ran the launch then fails (never a silent clamp)
+    int *ovf = nullptr;
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
+// largest magnitude the split-f16 format (hi + lo, both fp16) can hold
+constexpr float SPLIT_F16_MAX = 65504.0f;
 void launch_conv(const ConvParams &p, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
 // parity (py, px) see only a 2x2 window of the low-resolution input, with the 3x3 taps that land
@@ -113,9 +118,10 @@ void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, i
 // raw (optional, p != nullptr): additionally stores the un-normalised concatenation in the same
 // format (the input of a fused res_conv).
 // in_split: bit 0 / bit 1 = in0 / in1 is itself stored in the split-f16 format (split-only tensors)
+// ovf: range-check flag of the split format (see ConvParams::ovf), may be null
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
                      int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw = TDesc(),
-                     int in_split = 0);
+                     int in_split = 0, int *ovf = nullptr);
 // common power-of-two scale for several weight tensors: returns k with max|w| * 2^k in [1024, 2048)
 int split_scale_exponent(const float *packed, size_t n);
 float split_conv_weight_k(const float *packed, size_t rows, int CinPad, int k, float *dst);

@@ -109,6 +109,7 @@ class GaussianDiffusion(nn.Module):
             seed = self._draw_seed()
         eng.sample(cond_ptr, B, H, W, out.data_ptr(), nptr, seed, image_offset,
                    frames.data_ptr() if frames is not None else None)
+        self.denoise_fn.finish()
         return (out, frames) if continous else out
 
     @torch.no_grad()
@@ -117,13 +118,23 @@ class GaussianDiffusion(nn.Module):
         if continous else `ret_img[-1]` — the LAST image of the batch, shape [C,H,W]."""
         if not continous:
             return self.sample_batch(x_in, False, noise, seed)[-1]
+        if seed is None:
+            seed = self._draw_seed()
         out, frames = self.sample_batch(x_in, True, noise, seed)
         if self.conditional:
             first = x_in.to(torch.float32)
+        elif noise is not None:
+            # unconditional branch: ret_img starts with the initial noise image (diffusion.py:193-201,
+            # `img = torch.randn(shape); ret_img = img`) = slab 0 of the injected noise
+            first = noise[0].to(device=out.device, dtype=torch.float32)
         else:
-            # the reference starts ret_img with the initial noise here; it is not retrievable from
-            # the device RNG, so the first rows are the first recorded frame's shape of zeros
-            first = torch.zeros_like(out)
+            # device RNG: the initial image is draw 0 of every image's Philox stream
+            # (init_state_kernel); regenerate it from the same (seed, image index) keys
+            first = torch.empty_like(out)
+            eng, n = self._engine(), out[0].numel()
+            for i in range(out.shape[0]):
+                eng.philox_normal_into(seed, i, 0, n, first[i].data_ptr())
+            self.denoise_fn.finish()
         return torch.cat([first, frames.reshape(-1, *frames.shape[2:])], dim=0)
 
     @torch.no_grad()
@@ -156,6 +167,7 @@ class GaussianDiffusion(nn.Module):
         eng.sample_step(int(t), nz.data_ptr() if nz is not None else None)
         out = torch.empty_like(x)
         eng.sample_end(out.data_ptr())
+        self.denoise_fn.finish()
         return out
 
     # ---- small closed-form members kept for API completeness (diffusion.py:144-180) -------------

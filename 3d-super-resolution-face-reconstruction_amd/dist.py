@@ -72,4 +72,9 @@ def sharded_super_resolution(sample_fn: Callable[[torch.Tensor, int], torch.Tens
     rank = dist.get_rank() if dist.is_initialized() else 0
     a, b = shard_bounds(x_full.shape[0], world, rank)
     local = sample_fn(x_full[a:b], a)
+    if local.is_cuda:
+        # explicit dependency before the collective: the sampler may have run on the library's own
+        # stream, which RCCL's stream does not wait for (the torch facade already waits for it; a raw
+        # Engine-based sample_fn may not): wait for every stream of this device, once per call
+        torch.cuda.synchronize(local.device)
     return all_gather_images(local, x_full.shape[0]) if gather else local

@@ -175,10 +175,18 @@ class Engine:
     def sample_end(self, out_ptr: int):
         _lib.check(self.lib.sr3_sample_end(self.ctx, out_ptr))
 
+    def range_check(self) -> None:
+        """Raises Sr3Error if a split-f16 store left the fp16 range since the last check."""
+        _lib.check(self.lib.sr3_range_check(self.ctx))
+
     def philox_normal(self, seed: int, image: int, draw: int, n: int) -> np.ndarray:
         buf = self.buffer(n)
         _lib.check(self.lib.sr3_philox_normal(self.ctx, seed, image, draw, n, buf.ptr))
         return buf.download()
+
+    def philox_normal_into(self, seed: int, image: int, draw: int, n: int, out_ptr: int) -> None:
+        """Device Philox stream of (seed, image, draw) written to a device buffer (stream-ordered)."""
+        _lib.check(self.lib.sr3_philox_normal(self.ctx, seed, image, draw, n, out_ptr))
 
     # ---- pre-processing ---------------------------------------------------------------------
     def preprocess_bicubic(self, in_ptr: int, B: int, Hin: int, Win: int, Hout: int, Wout: int,

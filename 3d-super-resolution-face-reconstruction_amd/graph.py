@@ -167,3 +167,18 @@ def flops_per_image(cfg: UNetConfig, h: int, w: int) -> float:
             now_res *= 2
     fl += conv(pre, cfg.out_channel, 3, h, w)
     return fl
+
+
+def upsample_flops_per_image(cfg: UNetConfig, h: int, w: int) -> float:
+    """Algorithmic FLOPs of the `Upsample` convs alone (unet.py:58-65; part of flops_per_image).
+    The HIP path runs them as four sub-pixel 2x2 convs = 16/36 of these MACs, which the roofline's
+    `executed_frac` accounts for."""
+    inner, n = cfg.inner_channel, len(cfg.channel_mults)
+    div = 2 ** (n - 1)
+    h, w = h // div, w // div
+    fl = 0.0
+    for ind in reversed(range(1, n)):
+        ch = inner * cfg.channel_mults[ind]
+        h, w = 2 * h, 2 * w
+        fl += 2.0 * h * w * ch * ch * 9
+    return fl

@@ -22,10 +22,18 @@ def psnr(img1: np.ndarray, img2: np.ndarray) -> float:
     return 20 * math.log10(255.0 / math.sqrt(mse))
 
 
-def batch_psnr(a_nchw: np.ndarray, b_nchw: np.ndarray) -> float:
-    """Mean PSNR over a batch of [-1,1] images (inf if every image is identical after rounding)."""
+def batch_psnr_stats(a_nchw: np.ndarray, b_nchw: np.ndarray) -> dict:
+    """Per-batch PSNR summary of two batches of [-1,1] images: `mean_db` over the image pairs that
+    differ after uint8 rounding (None when there is none), `identical` = number of pairs that are
+    identical after rounding (their PSNR is infinite and is NOT part of the mean), `n` = pairs."""
     vals = [psnr(tensor2img(x), tensor2img(y)) for x, y in zip(a_nchw, b_nchw)]
     finite = [v for v in vals if math.isfinite(v)]
-    if not finite:
-        return float("inf")
-    return float(np.mean(finite)) if len(finite) == len(vals) else float(np.mean(finite))
+    return {"mean_db": float(np.mean(finite)) if finite else None,
+            "identical": len(vals) - len(finite), "n": len(vals)}
+
+
+def batch_psnr(a_nchw: np.ndarray, b_nchw: np.ndarray) -> float:
+    """Mean PSNR over the pairs that differ after rounding; inf if every pair is identical.
+    Pairs with infinite PSNR are excluded from the mean — use batch_psnr_stats to see how many."""
+    st = batch_psnr_stats(a_nchw, b_nchw)
+    return float("inf") if st["mean_db"] is None else st["mean_db"]

@@ -106,8 +106,21 @@ class UNet(nn.Module):
         self._sync_weights()
         if getattr(self._engine, "precision", None) != self.precision:
             self._engine.set_precision(self.precision)
-        self._engine.set_stream(torch.cuda.current_stream(idx).cuda_stream)
+        # Stream ordering, made explicit: on a non-default torch stream the library enqueues on that very
+        # stream. On the default (null) stream it uses its own stream (hipGraph capture is not allowed
+        # on the null stream), so pending torch work is waited for here and `finish()` waits for the
+        # library before torch (or a collective) touches the results.
+        cur = torch.cuda.current_stream(idx)
+        self._own_stream = cur.cuda_stream == 0
+        if self._own_stream:
+            cur.synchronize()
+        self._engine.set_stream(cur.cuda_stream)
         return self._engine
+
+    def finish(self) -> None:
+        """Call after enqueueing library work whose results torch will read (see engine())."""
+        if self._engine is not None and getattr(self, "_own_stream", True):
+            self._engine.synchronize()
 
     def _sync_weights(self) -> None:
         for name, p in self.named_parameters():
@@ -129,4 +142,5 @@ class UNet(nn.Module):
             raise RuntimeError(f"noise level must have {B} entries, got {nl.numel()}")
         out = torch.empty((B, self.cfg.out_channel, H, W), dtype=torch.float32, device=x.device)
         eng.unet_forward(x.data_ptr(), nl.data_ptr(), B, H, W, out.data_ptr())
+        self.finish()
         return out

@@ -79,6 +79,12 @@ def validate_batch(netG, sr: "torch.Tensor", hr: "torch.Tensor", samples: int = 
     x = sr.repeat(samples, 1, 1, 1)
     if seed is None:
         seed = netG._draw_seed()
+        if sharded and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # every rank must key the Philox streams with the SAME seed (image i's stream does not
+            # depend on the world size, dist.py): rank 0's draw wins
+            box = [seed]
+            torch.distributed.broadcast_object_list(box, src=0)
+            seed = int(box[0])
     if sharded:
         out = _dist.sharded_super_resolution(
             lambda xs, off: netG.super_resolution_batch(xs, seed=seed, image_offset=off), x)

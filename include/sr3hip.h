@@ -104,7 +104,8 @@ int sr3_set_schedule(sr3_ctx *ctx, int T, const float *noise_level, const float 
  *   out_dev    [B,C,H,W] final images (every image, not only ret_img[-1])
  *   frames_dev NULL or [n_frames,B,C,H,W]: the image after every step i with i % sample_inter == 0
  *              (:192,209-211), sample_inter = 1 | (T/10); n_frames = sr3_num_frames(ctx)
- * Stream-ordered; returns after enqueueing. */
+ * Stream-ordered. In f32 mode it returns after enqueueing; in split-f16 mode it synchronises at the
+ * end to read the range-check flag (sr3_range_check). */
 int sr3_sample(sr3_ctx *ctx, const float *cond_dev, int B, int H, int W, const float *noise_dev,
                uint64_t seed, uint64_t image_offset, float *out_dev, float *frames_dev);
 int sr3_num_frames(sr3_ctx *ctx);
@@ -115,6 +116,14 @@ int sr3_sample_begin(sr3_ctx *ctx, const float *cond_dev, int B, int H, int W,
                      const float *init_noise_dev, uint64_t seed, uint64_t image_offset);
 int sr3_sample_step(sr3_ctx *ctx, int t, const float *noise_slab_dev);
 int sr3_sample_end(sr3_ctx *ctx, float *out_dev);
+/* Range check of the split-f16 arithmetic (sr3_set_precision(ctx, 1)): the reference computes in
+ * fp32 (diffusion.py:164-180, unet.py:235-265) and has no such limit, so a value that does not fit
+ * the hi + lo fp16 operand format (|v| > 65504) must never pass silently. Every kernel that stores
+ * that format raises a device flag instead of clamping; sr3_sample_end, sr3_sample and
+ * sr3_unet_forward synchronise, read the flag and FAIL (the message names the f32 mode as the
+ * remedy). sr3_range_check does the same on demand between sr3_sample_step calls: 0 = in range,
+ * <0 = overflow since the last check (flag cleared). Synchronises the stream. */
+int sr3_range_check(sr3_ctx *ctx);
 
 /* The documented CPU twin of the device RNG is oracle/philox.py; this dumps the device stream for
  * comparison: n floats of draw `draw` for image `image`. */

@@ -130,7 +130,9 @@ def gen_unet(name, cfg, B, r, seed, with_taps=False):
     print(f"    ({time.time() - t0:.1f}s, eps std {eps.std():.3f})")
 
 
-def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True):
+def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True, frame_stride=1):
+    """frame_stride > 1 (large fixtures): the intermediate frames are stored sub-sampled
+    ([..., ::s, ::s]) as `frames_sub`; the final images (`final`, every pixel) and `last` stay whole."""
     t0 = time.time()
     netG = build_ref(cfg, sched, seed, conditional)
     T = sched["n_timestep"]
@@ -150,26 +152,56 @@ def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True):
             assert nf.k == T, nf.k
         with NoiseFeed(noise):
             last = netG.sample(batch_size=B, continous=False).numpy()
-    arrs.update(ret_img=ret, last=last,
-                meta=meta(cfg, B=B, r=r, l=l, seed=seed, conditional=conditional, schedule=sched))
+    if frame_stride > 1:
+        nf = ret.shape[0] // B - 1
+        fr = ret[B:].reshape(nf, B, 3, r, r)
+        arrs.update(frames_sub=fr[..., ::frame_stride, ::frame_stride].copy(), final=fr[-1].copy(), last=last,
+                    meta=meta(cfg, B=B, r=r, l=l, seed=seed, conditional=conditional, schedule=sched,
+                              frame_stride=frame_stride))
+    else:
+        arrs.update(ret_img=ret, last=last,
+                    meta=meta(cfg, B=B, r=r, l=l, seed=seed, conditional=conditional, schedule=sched))
     save(name, **arrs)
     fin = ret[-B:]
     print(f"    ({time.time() - t0:.1f}s, final std {fin.std():.3f}, saturated {np.mean(np.abs(fin) >= 1):.2%})")
 
 
+def only(name):
+    """python tests/golden/make_golden.py [fixture.npz ...] regenerates just the named fixtures."""
+    return len(sys.argv) < 2 or name in sys.argv[1:]
+
+
 if __name__ == "__main__":
-    print("schedules"); gen_schedules()
     tiny = synth.tiny_unet_config()
-    print("unet tiny"); gen_unet("unet_tiny.npz", tiny, B=2, r=16, seed=1, with_taps=True)
-    print("unet yml-literal r=16"); gen_unet("unet_yml224_r16.npz", synth.yml_unet_config(224), B=2, r=16, seed=2)
-    print("unet 128-variant r=32"); gen_unet("unet_yml128_r32.npz", synth.yml_unet_config(128), B=1, r=32, seed=3)
-    print("unet yml-literal r=128"); gen_unet("unet_yml224_r128.npz", synth.yml_unet_config(224), B=1, r=128, seed=4)
-    s20 = {"schedule": "linear", "n_timestep": 20, "linear_start": 1e-4, "linear_end": 2e-2}
-    print("sampler tiny"); gen_sampler("sampler_tiny.npz", tiny, s20, B=2, r=16, l=8, seed=5)
-    tiny_u = graph.UNetConfig(in_channel=3, out_channel=3, inner_channel=32, channel_mults=(1, 2),
-                              attn_res=(8,), res_blocks=1, dropout=0.0, image_size=16)
-    s10 = {"schedule": "cosine", "n_timestep": 10, "linear_start": 1e-4, "linear_end": 2e-2}
-    print("sampler tiny unconditional"); gen_sampler("sampler_uncond_tiny.npz", tiny_u, s10, B=2, r=16, l=0, seed=6, conditional=False)
-    # BASELINE.json config 1: sr_sr3_VGGF2_8_16, batch 4, 100-step DDPM (config/sr_sr3_VGGF2_8_16_model2.yml:52-57)
     s100 = {"schedule": "linear", "n_timestep": 100, "linear_start": 1e-6, "linear_end": 1e-2}
-    print("sampler config 1"); gen_sampler("sampler_cfg1_8_16.npz", synth.yml_unet_config(224), s100, B=4, r=16, l=8, seed=7)
+    if only("schedules.npz"):
+        print("schedules"); gen_schedules()
+    if only("unet_tiny.npz"):
+        print("unet tiny"); gen_unet("unet_tiny.npz", tiny, B=2, r=16, seed=1, with_taps=True)
+    if only("unet_yml224_r16.npz"):
+        print("unet yml-literal r=16"); gen_unet("unet_yml224_r16.npz", synth.yml_unet_config(224), B=2, r=16, seed=2)
+    if only("unet_yml128_r32.npz"):
+        print("unet 128-variant r=32"); gen_unet("unet_yml128_r32.npz", synth.yml_unet_config(128), B=1, r=32, seed=3)
+    if only("unet_yml224_r128.npz"):
+        print("unet yml-literal r=128"); gen_unet("unet_yml224_r128.npz", synth.yml_unet_config(224), B=1, r=128, seed=4)
+    if only("unet_yml128_r128.npz"):
+        # BASELINE.json config 3 ("attention-heavy"): image_size=128 puts attention at the 16x16 level
+        # (N = 256 tokens x 5 modules + mid), reference placement logic unet.py:192-207
+        print("unet 128-variant r=128"); gen_unet("unet_yml128_r128.npz", synth.yml_unet_config(128), B=1, r=128, seed=8)
+    if only("sampler_tiny.npz"):
+        s20 = {"schedule": "linear", "n_timestep": 20, "linear_start": 1e-4, "linear_end": 2e-2}
+        print("sampler tiny"); gen_sampler("sampler_tiny.npz", tiny, s20, B=2, r=16, l=8, seed=5)
+    if only("sampler_uncond_tiny.npz"):
+        tiny_u = graph.UNetConfig(in_channel=3, out_channel=3, inner_channel=32, channel_mults=(1, 2),
+                                  attn_res=(8,), res_blocks=1, dropout=0.0, image_size=16)
+        s10 = {"schedule": "cosine", "n_timestep": 10, "linear_start": 1e-4, "linear_end": 2e-2}
+        print("sampler tiny unconditional"); gen_sampler("sampler_uncond_tiny.npz", tiny_u, s10, B=2, r=16, l=0, seed=6, conditional=False)
+    if only("sampler_cfg1_8_16.npz"):
+        # BASELINE.json config 1: sr_sr3_VGGF2_8_16, batch 4, 100-step DDPM (config/sr_sr3_VGGF2_8_16_model2.yml:52-57)
+        print("sampler config 1"); gen_sampler("sampler_cfg1_8_16.npz", synth.yml_unet_config(224), s100, B=4, r=16, l=8, seed=7)
+    if only("sampler_cfg5_32_128.npz"):
+        # the benchmarked resolution over a whole schedule: BASELINE.json config 5's SR stage
+        # (sr_sr3_VGGF2_32_128: 32 -> 128, T = 100, config/sr_sr3_VGGF2_32_128_model3.yml), B = 2,
+        # yml-literal UNet; intermediate frames stored sub-sampled (every 4th pixel per axis)
+        print("sampler config 5 (128x128, T=100)")
+        gen_sampler("sampler_cfg5_32_128.npz", synth.yml_unet_config(224), s100, B=2, r=128, l=32, seed=9, frame_stride=4)

@@ -40,7 +40,7 @@ def test_param_inventory_matches_reference_state_dict():
 
 @pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", ["unet_tiny.npz", "unet_yml224_r16.npz", "unet_yml128_r32.npz",
-                                  "unet_yml224_r128.npz"])
+                                  "unet_yml224_r128.npz", "unet_yml128_r128.npz"])
 def test_unet_forward_golden(name, prec):
     g = load_golden(name)
     cfg = cfg_from_meta(g["meta"])

@@ -30,7 +30,8 @@ def test_unknown_schedule_raises():
 
 
 @pytest.mark.parametrize("name,tol", [("unet_tiny.npz", 2e-5), ("unet_yml224_r16.npz", 2e-5),
-                                      ("unet_yml128_r32.npz", 2e-5), ("unet_yml224_r128.npz", 2e-5)])
+                                      ("unet_yml128_r32.npz", 2e-5), ("unet_yml224_r128.npz", 2e-5),
+                                      ("unet_yml128_r128.npz", 2e-5)])
 def test_unet_forward_matches_reference(name, tol):
     g = load_golden(name)
     cfg = cfg_from_meta(g["meta"])
@@ -61,6 +62,27 @@ def test_sampler_matches_reference(name):
     assert ret.shape == g["ret_img"].shape
     np.testing.assert_allclose(ret, g["ret_img"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(final[-1], g["last"], atol=1e-4, rtol=0)
+
+
+def test_sampler_128px_head_matches_reference():
+    """BASELINE config 5's SR stage at the benchmarked resolution (32 -> 128, T = 100, B = 2): the
+    oracle is run up to the FIRST recorded frame (10 of the 100 steps, ~30 s of numpy at 128x128;
+    the whole loop is the GPU test's job) and compared with the reference's frame."""
+    g = load_golden("sampler_cfg5_32_128.npz")
+    m = g["meta"]
+    cfg = cfg_from_meta(m)
+    sd = synth.synth_state_dict(cfg, m["seed"])
+    sch = oracle.noise_schedule(m["schedule"])
+    B, r, T, st = m["B"], m["r"], m["schedule"]["n_timestep"], m["frame_stride"]
+    noise = synth.synth_noise(T, B, 3, r, r, m["seed"])
+    np.testing.assert_array_equal(g["cond"], synth.synth_cond(B, r, m["l"], m["seed"]))
+    assert g["frames_sub"].shape == (10, B, 3, r // st, r // st) and g["final"].shape == (B, 3, r, r)
+    np.testing.assert_array_equal(g["final"][..., ::st, ::st], g["frames_sub"][-1])
+    np.testing.assert_array_equal(g["final"][-1], g["last"])
+    x = noise[0]
+    for k, t in enumerate(range(T - 1, T - 11, -1)):     # t = 99 .. 90; frame 0 is recorded after t = 90
+        x = oracle.p_sample(sd, cfg, sch, x, t, g["cond"], noise[k + 1])
+    np.testing.assert_allclose(x[..., ::st, ::st], g["frames_sub"][0], atol=1e-4, rtol=0)
 
 
 def test_pil_bicubic_restatement_bit_exact():
