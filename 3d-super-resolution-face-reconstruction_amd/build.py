@@ -30,9 +30,17 @@ def _stale(out: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+    """experiments=True builds libsr3hip_exp.so with -DSR3_EXPERIMENTS: the timing switches of
+    tools/conv_bench.py (SR3_CONV_DBG) exist only there, never in the product library."""
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    # SR3_EXP_TAG / SR3_EXP_DEFINES (experiments only): several variant libraries side by side, e.g.
+    #   SR3_EXP_TAG=v1 SR3_EXP_DEFINES="-DSR3_GA_VARIANT=1" python build.py --experiments  -> libsr3hip_exp_v1.so
+    tag = os.environ.get("SR3_EXP_TAG", "") if experiments else ""
+    extra = os.environ.get("SR3_EXP_DEFINES", "").split() if experiments else []
+    objdir = os.path.join(HERE, ("build_exp" + ("_" + tag if tag else "")) if experiments else "build")
+    lib = os.path.join(HERE, "libsr3hip_exp%s.so" % ("_" + tag if tag else "")) if experiments else LIB
+    flags = FLAGS + (["-DSR3_EXPERIMENTS"] + extra if experiments else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "sr3_internal.h"),
                os.path.join(HERE, "..", "include", "sr3hip.h")]
@@ -43,7 +51,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", sp, "-o", obj])
+            jobs.append([hipcc, *flags, "-c", sp, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -55,10 +63,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

@@ -774,7 +774,8 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
             static_for<TAPS>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int dy = tap / KS, dx = tap % KS;
-                if (dx == 1) {          // the stage of group g-1 is free once K-step KS*g - 1 has been read
+                const bool feed = !(SR3_DBG(p) & 1) || k == 0;      // experiment: operands only for the first K-step
+                if (dx == 1 && feed) {  // the stage of group g-1 is free once K-step KS*g - 1 has been read
                     if (dy < KS - 1) {
                         SR3_ISSUE_HALO(c0, dy + 1)
                     } else if (c0 + BK < Cin) {
@@ -783,11 +784,13 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
                 }
                 float *Bd = Bring + (k & 1) * BSTG + w * 256;
                 const char *wb = wbase + (size_t)tap * tapstride * 4;
-                static_for<BR>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
-                });
-                producer_sync<0>();
+                if (feed) {
+                    static_for<BR>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                    });
+                }
+                if (!(SR3_DBG(p) & 8)) producer_sync<0>();          // experiment bit 3: no barriers (timing only)
                 ++k;
             });
         }
@@ -844,6 +847,30 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
             rhalo[mt] = rplain[mt] + HALO * (rplain[mt] / SEG);
         }
         h16x8 ah[MT], al[MT], bqh[2], bql[2];
+#ifndef SR3_CONV_VARIANT
+#define SR3_CONV_VARIANT 1
+#endif
+#if SR3_CONV_VARIANT >= 2
+        __builtin_amdgcn_s_setprio(1);      // consumers win issue arbitration against the DMA waves
+#endif
+        const float *aptr_h[MT], *aptr_l[MT];   // variant >= 1: fragment addresses of the NEXT K-step, computed early
+#define SR3_AADDR(MTI, KT)                                                                         \
+    {                                                                                              \
+        const int kt_ = (KT);                                                                      \
+        const bool halo_ = kt_ < nkh;                                                              \
+        const int g_ = kt_ / KS;                                                                   \
+        const int astage_ = halo_ ? (g_ & 1) : ((G + kt_ - nkh) & 1);                              \
+        const int R_ = halo_ ? rhalo[MTI] + (kt_ - KS * g_) : rplain[MTI];                         \
+        const int sw_ = (R_ >> 1) & 7;                                                             \
+        const float *Ar_ = Aring + astage_ * ASTG + R_ * ROWF;                                     \
+        aptr_h[MTI] = Ar_ + ((q ^ sw_) & 7) * 4;                                                   \
+        aptr_l[MTI] = Ar_ + (((4 + q) ^ sw_) & 7) * 4;                                             \
+    }
+#define SR3_AREAD2(MTI)                                                                            \
+    {                                                                                              \
+        ah[MTI] = *reinterpret_cast<const h16x8 *>(aptr_h[MTI]);                                   \
+        al[MTI] = *reinterpret_cast<const h16x8 *>(aptr_l[MTI]);                                   \
+    }
 #define SR3_AREAD(MTI, KT)                                                                         \
     {                                                                                              \
         const int kt_ = (KT);                                                                      \
@@ -872,23 +899,59 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) SR3_AREAD(mt, 0)
         SR3_BREAD(0, 0, 0)
+#ifdef SR3_EXPERIMENTS
+        // timing experiments (results are wrong): bit 2 no fragment reads after the first K-step,
+        // bit 3 no barriers, bit 4 no MFMAs
+        const bool x_rd = !(p.dbg & 4), x_bar = !(p.dbg & 8), x_mma = !(p.dbg & 16);
+#else
+        constexpr bool x_rd = true, x_bar = true, x_mma = true;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             const int kn = min(kt + 1, nk - 1);     // after the last K-step: re-read, unused
+#if SR3_CONV_VARIANT >= 1
+            // the next K-step's A addresses are computed in the shadow of the first columns' MFMAs and
+            // the reads are pinned right behind the last MFMA that uses each fragment (left to itself
+            // the scheduler sinks address arithmetic and reads to the top of the next iteration, in
+            // front of the MFMAs that wait for them)
 #pragma unroll
             for (int nt = 0; nt < NT - 1; ++nt) {
                 SR3_BREAD((nt + 1) & 1, nt + 1, kt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) SR3_MMA16(mt, nt, nt & 1)
+                if (nt == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) SR3_AADDR(mt, kn)
+                }
             }
-            __syncthreads();                        // every read of K-step kt has been issued and waited
+            __syncthreads();
             SR3_BREAD(0, 0, kn)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 SR3_MMA16(mt, NT - 1, (NT - 1) & 1)
-                SR3_AREAD(mt, kn)
+                __builtin_amdgcn_sched_barrier(0);
+                SR3_AREAD2(mt)
+                __builtin_amdgcn_sched_barrier(0);
             }
+#else
+#pragma unroll
+            for (int nt = 0; nt < NT - 1; ++nt) {
+                if (x_rd) SR3_BREAD((nt + 1) & 1, nt + 1, kt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) if (x_mma) SR3_MMA16(mt, nt, nt & 1)
+            }
+            if (x_bar) __syncthreads();             // every read of K-step kt has been issued and waited
+            if (x_rd) SR3_BREAD(0, 0, kn)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (x_mma) SR3_MMA16(mt, NT - 1, (NT - 1) & 1)
+                if (x_rd) SR3_AREAD(mt, kn)
+            }
+#endif
         }
 #undef SR3_AREAD
+#undef SR3_AREAD2
+#undef SR3_AADDR
 #undef SR3_BREAD
 #undef SR3_MMA16
 #pragma unroll

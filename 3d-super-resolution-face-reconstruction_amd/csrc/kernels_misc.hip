@@ -8,6 +8,7 @@ namespace sr3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // =================================================================================================
 // GroupNorm statistics -> folded per-(image, channel) affine
@@ -201,12 +202,189 @@ __device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8], f
     }
 }
 
+// Where the per-(image, channel) GroupNorm statistics of an apply pass come from: fp64 {sum, sum of
+// squares} partials per (image, slice, channel) of one or two source tensors (the halves of a
+// concatenation; written by conv epilogues or by gn_partial_kernel), folded with gamma / beta.
+struct GnFold {
+    const double *p0 = nullptr, *p1 = nullptr;
+    int C0 = 0, slices0 = 0, C1 = 0, slices1 = 0;
+    const float *gamma = nullptr, *beta = nullptr;
+    float eps = 0.f;
+    int groups = 0, HW = 0;
+};
+
+constexpr int GA_T = 512;      // threads per block of the apply pass
+
+// One block = `ppb` consecutive pixels of one image, all channels; a thread owns 8 consecutive
+// channels of a pixel per iteration (two 16-B loads, 16-B stores). The prologue folds the
+// GroupNorm FINALIZE into the pass (it used to be a launch of its own in front of every apply):
+// per channel it adds the slices, assembles groups from channels (any group size, groups may
+// straddle the x / skip boundary of a concatenation), and leaves scale = rstd * gamma,
+// shift = beta - mean * scale in LDS. Deterministic (fixed summation order, no atomics).
+// MODE 0 copy, 1 affine, 2 affine + Swish; scale/shift != null: take them from memory instead.
 template <int MODE, int SPLIT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TDesc in1,
-                                                       const float *__restrict__ scale,
-                                                       const float *__restrict__ shift, const TDesc out,
-                                                       const TDesc raw, const int in_split, int *ovf) {
-    // a thread owns 8 consecutive channels of one pixel (two 16-B loads, 16-B stores);
+__global__ __launch_bounds__(GA_T) void gn_apply_kernel(const TDesc in0, const TDesc in1,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, const GnFold st,
+                                                         const TDesc out, const TDesc raw, const int in_split,
+                                                         int *ovf, const int ppb) {
+    extern __shared__ __attribute__((aligned(16))) float ga_smem[];
+    const int C0 = in0.C, C = out.C, C8 = C >> 3;
+    const int n = blockIdx.y, t = threadIdx.x;
+    float *sc = ga_smem, *sh = ga_smem + C;             // [C] each
+    if (MODE != 0) {
+        if (scale != nullptr) {
+            for (int c = t; c < C; c += GA_T) { sc[c] = scale[(size_t)n * C + c]; sh[c] = shift[(size_t)n * C + c]; }
+        } else {
+            double2 *chs = reinterpret_cast<double2 *>(ga_smem + 2 * C);    // [C] per-channel totals
+            double2 *red = chs + C;                                         // [GA_T]
+            float *gm = reinterpret_cast<float *>(red + GA_T), *gr = gm + st.groups;
+            const int CP = min(C, GA_T), L = GA_T / CP;                     // slice lanes per channel
+            for (int cbase = 0; cbase < C; cbase += CP) {
+                const int c = cbase + t % CP, l = t / CP;
+                double a = 0, b = 0;
+                if (l < L && c < C) {
+                    const bool first = c < st.C0;
+                    const double *pp = first ? st.p0 : st.p1;
+                    const int Cs = first ? st.C0 : st.C1, cl = first ? c : c - st.C0, sl = first ? st.slices0 : st.slices1;
+                    const double *base = pp + ((size_t)n * sl * Cs + cl) * 2;
+                    const size_t stride = (size_t)Cs * 2;                   // doubles between slices
+                    int s = l;
+                    // eight loads in flight per thread (a plain loop waits for every load before the next);
+                    // summed in slice order: deterministic
+                    for (; s + 7 * L < sl; s += 8 * L) {
+                        double2 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(base + (size_t)(s + u * L) * stride);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+                    }
+                    for (; s < sl; s += L) {
+                        const double2 v = *reinterpret_cast<const double2 *>(base + (size_t)s * stride);
+                        a += v.x; b += v.y;
+                    }
+                }
+                red[t] = make_double2(a, b);
+                __syncthreads();
+                if (t < CP && cbase + t < C) {
+                    double sa = 0, sb = 0;
+                    for (int l2 = 0; l2 < L; ++l2) { const double2 v = red[l2 * CP + t]; sa += v.x; sb += v.y; }
+                    chs[cbase + t] = make_double2(sa, sb);
+                }
+                __syncthreads();
+            }
+            const int Cg = C / st.groups;
+            for (int g = t; g < st.groups; g += GA_T) {
+                double sa = 0, sb = 0;
+                for (int cc = 0; cc < Cg; ++cc) { const double2 v = chs[g * Cg + cc]; sa += v.x; sb += v.y; }
+                const double cnt = (double)Cg * st.HW;
+                const double mean = sa / cnt;
+                const double var = fmax(sb / cnt - mean * mean, 0.0);
+                gm[g] = (float)mean;
+                gr[g] = 1.0f / sqrtf((float)var + st.eps);
+            }
+            __syncthreads();
+            for (int c = t; c < C; c += GA_T) {
+                const int g = c / Cg;
+                const float v = gr[g] * st.gamma[c];
+                sc[c] = v;
+                sh[c] = st.beta[c] - gm[g] * v;
+            }
+        }
+        __syncthreads();
+    }
+    // thread = (pixel lane, channel octet): the octet and its scale / shift stay in registers, the pixel
+    // advances by `rows` per iteration (no division in the loop)
+    const int W = out.W, HW = out.H * W;
+    const int TC = min(C8, GA_T), rows = GA_T / TC;
+    const int pl = t / TC;
+    if (pl >= rows) return;
+    const int pix0 = blockIdx.x * ppb, pix1 = min(HW, pix0 + ppb);
+    float absmax = 0.f;
+    for (int c = (t - pl * TC) << 3; c < C; c += TC << 3) {       // one pass unless C8 > GA_T
+        float scv[8], shv[8];
+        if (MODE != 0) {
+            const float4 s0 = *reinterpret_cast<const float4 *>(sc + c), s1 = *reinterpret_cast<const float4 *>(sc + c + 4);
+            const float4 h0 = *reinterpret_cast<const float4 *>(sh + c), h1 = *reinterpret_cast<const float4 *>(sh + c + 4);
+            scv[0] = s0.x; scv[1] = s0.y; scv[2] = s0.z; scv[3] = s0.w; scv[4] = s1.x; scv[5] = s1.y; scv[6] = s1.z; scv[7] = s1.w;
+            shv[0] = h0.x; shv[1] = h0.y; shv[2] = h0.z; shv[3] = h0.w; shv[4] = h1.x; shv[5] = h1.y; shv[6] = h1.z; shv[7] = h1.w;
+        }
+        // in_split bit 0 / 1: in0 / in1 is stored in the split-f16 format (a conv wrote only the twin of
+        // its output): x = hi + lo, exact to ~2^-22 |x|
+        const bool first = c < C0;
+        const int cl = first ? c : c - C0;
+        const bool src_split = (in_split >> (first ? 0 : 1)) & 1;
+        const TDesc &src = first ? in0 : in1;
+        const size_t Cs = src.C;
+        // two pixels per iteration: both loads are issued before either is used (twice the bytes in
+        // flight per thread; a single-item loop waits for its load before the next one is issued)
+        struct Item { f32x4v a, b; };
+        auto load = [&](int y, int x) -> Item {
+            const float *pixp = src.p + src.pix(n, y, x) * Cs;
+            Item it;
+            if (src_split) {
+                const _Float16 *hp = reinterpret_cast<const _Float16 *>(pixp + (cl & ~31)) + (cl & 31);
+                it.a = *reinterpret_cast<const f32x4v *>(hp);            // 8 hi halfs
+                it.b = *reinterpret_cast<const f32x4v *>(hp + 32);       // 8 lo halfs
+            } else {
+                it.a = *reinterpret_cast<const f32x4v *>(pixp + cl);
+                it.b = *reinterpret_cast<const f32x4v *>(pixp + cl + 4);
+            }
+            return it;
+        };
+        auto finish = [&](const Item &it, int y, int x) {
+            float f[8];
+            if (src_split) {
+                const h16x8 hi = __builtin_bit_cast(h16x8, it.a), lo = __builtin_bit_cast(h16x8, it.b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (float)hi[j] + (float)lo[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = it.a[j]; f[4 + j] = it.b[j]; }
+            }
+            if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f, absmax);
+            if (MODE != 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], scv[j], shv[j]);
+            }
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
+            }
+            store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
+        };
+        int pix = pix0 + pl;
+        int y = pix / W, x = pix - y * W;
+        for (; pix + rows < pix1; pix += 2 * rows) {
+            int x2 = x + rows, y2 = y;
+            while (x2 >= W) { x2 -= W; ++y2; }
+            const Item i0 = load(y, x), i1 = load(y2, x2);
+            finish(i0, y, x);
+            finish(i1, y2, x2);
+            x = x2 + rows; y = y2;
+            while (x >= W) { x -= W; ++y; }
+        }
+        for (; pix < pix1; pix += rows) {       // tail
+            finish(load(y, x), y, x);
+            x += rows;
+            while (x >= W) { x -= W; ++y; }
+        }
+    }
+    if (SPLIT && ovf != nullptr && absmax > SPLIT_F16_MAX) *ovf = 1;
+}
+
+} // namespace
+
+namespace {
+// Streaming form for LARGE tensors: one (pixel, channel octet) per thread, no loop, scale / shift read from
+// memory (written by gn_finalize_kernel). On tensors of hundreds of MB it streams ~10 % faster than the
+// folded form above (whose per-block prologue re-reads the partial statistics), which more than pays
+// for the separate finalize launch; the folded form wins wherever a launch is latency bound.
+template <int MODE, int SPLIT>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, const TDesc in1,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, const TDesc out,
+                                                            const TDesc raw, const int in_split, int *ovf) {
     // grid: x = chunks of (pixel-in-row, channel octet), y = n * H + row
     const int C0 = in0.C, C = out.C, C8 = C >> 3;
     const int n = blockIdx.y / out.H, y = blockIdx.y - n * out.H;
@@ -214,8 +392,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
     if (item >= out.W * C8) return;
     const int x = item / C8;
     const int c = (item - x * C8) << 3;
-    // in_split bit 0 / 1: in0 / in1 is stored in the split-f16 format (a conv wrote only the twin of
-    // its output): x = hi + lo, exact to ~2^-22 |x|
     const bool first = c < C0;
     const int cl = first ? c : c - C0;
     const float *pixp = first ? in0.p + in0.pix(n, y, x) * C0 : in1.p + in1.pix(n, y, x) * in1.C;
@@ -236,10 +412,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
         const float *scp = scale + (size_t)n * C + c, *shp = shift + (size_t)n * C + c;
         const float4 s0 = *reinterpret_cast<const float4 *>(scp), s1 = *reinterpret_cast<const float4 *>(scp + 4);
         const float4 h0 = *reinterpret_cast<const float4 *>(shp), h1 = *reinterpret_cast<const float4 *>(shp + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], sc[j], sh[j]);
+        for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], scv[j], shv[j]);
     }
     if (MODE == 2) {
 #pragma unroll
@@ -248,20 +424,85 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TDesc in0, const TD
     store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
     if (SPLIT && ovf != nullptr && absmax > SPLIT_F16_MAX) *ovf = 1;
 }
-
 } // namespace
+
+void launch_gn_apply_rows(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
+                          int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw, int in_split, int *ovf) {
+    const int items = out.W * (out.C >> 3);
+    const dim3 grid((items + 255) / 256, B * out.H);
+#define SR3_GR(M, S) hipLaunchKernelGGL((gn_apply_rows_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf)
+    if (split) {
+        if (mode == 0) SR3_GR(0, 1); else if (mode == 1) SR3_GR(1, 1); else SR3_GR(2, 1);
+    } else {
+        if (mode == 0) SR3_GR(0, 0); else if (mode == 1) SR3_GR(1, 0); else SR3_GR(2, 0);
+    }
+#undef SR3_GR
+}
+
+// pixels per block: enough blocks to keep every CU streaming (>= ~4 blocks of 512 threads per CU over
+// the whole grid), at least two items per thread
+static int ga_pixels_per_block(int B, int HW, int C8) {
+    int P = (1024 + B - 1) / B;                         // blocks per image wanted
+    const int maxP = (HW * C8 + 2 * GA_T - 1) / (2 * GA_T);
+    if (P > maxP) P = maxP;
+    if (P < 1) P = 1;
+    return (HW + P - 1) / P;
+}
+
+static void launch_gn_apply_impl(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
+                                 const GnFold &st, int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw,
+                                 int in_split, int *ovf) {
+    const int HW = out.H * out.W, C = out.C;
+    const int ppb = ga_pixels_per_block(B, HW, C >> 3);
+    const dim3 grid((HW + ppb - 1) / ppb, B);
+    // LDS: scale / shift [C] floats; fold scratch: per-channel totals [C] + lanes [GA_T] double2, group mean / rstd
+    const size_t lds = mode == 0 ? 16 : ((size_t)2 * C * sizeof(float) +
+                       (scale ? 0 : ((size_t)C + GA_T) * sizeof(double2) + (size_t)2 * st.groups * sizeof(float)));
+#define SR3_GA(M, S)                                                                                               \
+    {                                                                                                              \
+        static size_t attr = 48 * 1024;                                                                            \
+        if (lds > attr) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gn_apply_kernel<M, S>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+            attr = lds;                                                                                            \
+        }                                                                                                          \
+        hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(GA_T), lds, s, in0, in1, scale, shift, st, out, raw, \
+                           in_split, ovf, ppb);                                                                    \
+    }
+    if (split) {
+        if (mode == 0) SR3_GA(0, 1) else if (mode == 1) SR3_GA(1, 1) else SR3_GA(2, 1)
+    } else {
+        if (mode == 0) SR3_GA(0, 0) else if (mode == 1) SR3_GA(1, 0) else SR3_GA(2, 0)
+    }
+#undef SR3_GA
+}
 
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
                      int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw, int in_split, int *ovf) {
-    const int items = out.W * (out.C >> 3);
-    const dim3 grid((items + 255) / 256, B * out.H);
-#define SR3_GA(M, S) hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf)
-    if (split) {
-        if (mode == 0) SR3_GA(0, 1); else if (mode == 1) SR3_GA(1, 1); else SR3_GA(2, 1);
-    } else {
-        if (mode == 0) SR3_GA(0, 0); else if (mode == 1) SR3_GA(1, 0); else SR3_GA(2, 0);
-    }
-#undef SR3_GA
+    launch_gn_apply_impl(in0, in1, B, scale, shift, GnFold(), mode, split, out, s, raw, in_split, ovf);
+}
+
+// GroupNorm (statistics already accumulated as partials) + affine (+ Swish) (+ concat) in ONE launch
+void launch_gn_fold_apply(const TDesc &in0, const TDesc &in1, int B, const StatsRef &s0, const StatsRef &s1, int groups,
+                          const float *gamma, const float *beta, float eps, int mode, int split, const TDesc &out,
+                          hipStream_t s, const TDesc &raw, int in_split, int *ovf) {
+    GnFold st;
+    st.p0 = s0.p; st.C0 = in0.C; st.slices0 = s0.slices;
+    st.p1 = s1.p; st.C1 = in1.p ? in1.C : 0; st.slices1 = s1.slices;
+    if (in1.p && !s1.p) { st.C0 = in0.C + in1.C; st.C1 = 0; }      // s0 describes the whole concatenation
+    st.gamma = gamma; st.beta = beta; st.eps = eps; st.groups = groups; st.HW = in0.H * in0.W;
+    launch_gn_apply_impl(in0, in1, B, nullptr, nullptr, st, mode, split, out, s, raw, in_split, ovf);
+}
+
+// statistics by the streaming kernel (tensors whose producer could not fuse them): partials of the
+// virtual concatenation as ONE source with C0 + C1 channels
+StatsRef launch_groupnorm_partials(const TDesc &in0, const TDesc &in1, int B, float *part, hipStream_t s) {
+    const int HW = in0.H * in0.W;
+    const int slices = gn_slices(B, HW);
+    double *dpart = reinterpret_cast<double *>(part);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, B), dim3(256), 0, s, in0, in1, slices, dpart);
+    StatsRef r; r.p = dpart; r.slices = slices;
+    return r;
 }
 
 // =================================================================================================

@@ -584,13 +584,27 @@ const TDesc kNone{};
 void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act,
                 const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc(), int in_split = 0) {
     c->pbegin(F_GN);
-    if (sa.p && (!b.p || sb.p) && !c->no_fused_stats)
-        launch_groupnorm_finalize(sa, a.C, sb, b.p ? b.C : 0, B, a.H * a.W, c->cfg.norm_groups,
-                                  c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f, c->gscale, c->gshift, c->stream);
-    else
-        launch_groupnorm_affine(a, b, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
-                                c->gpart, c->gscale, c->gshift, c->stream);
-    launch_gn_apply(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split, c->d_ovf);
+    const float *gamma = c->params[g.gamma].dev, *beta = c->params[g.beta].dev;
+    // bytes the pass moves (read + write, 4 B per element each way): above ~200 MB the one-item-per-thread
+    // streaming kernel behind a separate finalize launch is faster than the folded form (A/B on one box,
+    // profiles/README.md); below it the launch saved and the shorter critical path win
+    const double pass_bytes = 8.0 * B * a.H * a.W * (a.C + (b.p ? b.C : 0));
+    static const double fold_max = getenv("SR3_GN_FOLD_MAX_MB") ? atof(getenv("SR3_GN_FOLD_MAX_MB")) * 1e6 : 200e6;
+    if (sa.p && (!b.p || sb.p) && !c->no_fused_stats && pass_bytes > fold_max) {
+        launch_groupnorm_finalize(sa, a.C, sb, b.p ? b.C : 0, B, a.H * a.W, c->cfg.norm_groups, gamma, beta, 1e-5f,
+                                  c->gscale, c->gshift, c->stream);
+        launch_gn_apply_rows(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split, c->d_ovf);
+    } else if (sa.p && (!b.p || sb.p) && !c->no_fused_stats) {
+        // statistics came out of the producing convs' epilogues: finalize + apply are ONE launch
+        launch_gn_fold_apply(a, b, B, sa, sb, c->cfg.norm_groups, gamma, beta, 1e-5f, mode, c->prec, act, c->stream, raw,
+                             in_split, c->d_ovf);
+    } else {
+        // fallback: streaming statistics kernel over the (fp32) tensors; its partials describe the
+        // virtual concatenation as one source of a.C + b.C channels
+        const StatsRef sp = launch_groupnorm_partials(a, b, B, c->gpart, c->stream);
+        launch_gn_fold_apply(a, b, B, sp, StatsRef(), c->cfg.norm_groups, gamma, beta, 1e-5f, mode, c->prec, act, c->stream,
+                             raw, in_split, c->d_ovf);
+    }
     c->pend();
 }
 
@@ -701,7 +715,7 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
             if (c->prec) {      // the 6 (of 32 padded) input channels in split-f16 form: the first conv then runs
                                 // on the fast path too instead of 9 mostly-zero K-steps of f32 MFMA
                 c->pbegin(F_GN);
-                launch_gn_apply(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream, TDesc(), 0, c->d_ovf);
+                launch_gn_apply_rows(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream, TDesc(), 0, c->d_ovf);
                 c->pend();
                 run_conv(c, c->x0s, kNone, m.conv, B, 1, 0, nullptr, kNone, m.out, true, kNone, nullptr, nullptr, m.st_out, m.out_s,
                          kNone, !(so_mode && m.out_s.p));

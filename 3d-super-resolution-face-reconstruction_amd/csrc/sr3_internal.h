@@ -122,6 +122,18 @@ void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, i
 void launch_gn_apply(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
                      int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw = TDesc(),
                      int in_split = 0, int *ovf = nullptr);
+// streaming form of the apply pass for large tensors (one item per thread; scale / shift from memory)
+void launch_gn_apply_rows(const TDesc &in0, const TDesc &in1, int B, const float *scale, const float *shift,
+                          int mode, int split, const TDesc &out, hipStream_t s, const TDesc &raw = TDesc(),
+                          int in_split = 0, int *ovf = nullptr);
+// GroupNorm finalize folded into the apply pass (one launch per normalised tensor): s0 / s1 are the fp64
+// partial statistics of in0 / in1 (ConvParams::stats layout; from conv epilogues or
+// launch_groupnorm_partials, which returns the virtual concatenation as one source: pass it as s0
+// with s1 empty)
+void launch_gn_fold_apply(const TDesc &in0, const TDesc &in1, int B, const StatsRef &s0, const StatsRef &s1, int groups,
+                          const float *gamma, const float *beta, float eps, int mode, int split, const TDesc &out,
+                          hipStream_t s, const TDesc &raw = TDesc(), int in_split = 0, int *ovf = nullptr);
+StatsRef launch_groupnorm_partials(const TDesc &in0, const TDesc &in1, int B, float *part, hipStream_t s);
 // common power-of-two scale for several weight tensors: returns k with max|w| * 2^k in [1024, 2048)
 int split_scale_exponent(const float *packed, size_t n);
 float split_conv_weight_k(const float *packed, size_t rows, int CinPad, int k, float *dst);
