@@ -12,8 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsr3hip.so")
-SOURCES = ["sr3_api.hip", "kernels_conv.hip", "kernels_misc.hip", "kernels_pre.hip", "kernels_post.hip"]
+SOURCES = ["sr3_api.hip", "kernels_conv.hip", "kernels_misc.hip", "kernels_edge.hip", "kernels_pre.hip", "kernels_post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source flags: the fp32 VALU contraction of kernels_edge.hip must stay scalar v_fma_f32 (the SLP
+# vectoriser packs it into v_pk_fma_f32 pairs: register-pair shuffles, 2 KB of scratch per lane)
+EXTRA_FLAGS = {"kernels_edge.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -51,7 +54,7 @@ def build_library(force: bool = False, verbose: bool = False, experiments: bool 
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            jobs.append([hipcc, *flags, "-c", sp, "-o", obj])
+            jobs.append([hipcc, *flags, *EXTRA_FLAGS.get(src, []), "-c", sp, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -292,31 +292,30 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
         __builtin_amdgcn_sched_barrier(0);
     }
     // 5. split-f16 twin: per 32-channel chunk 32 hi halfs | 32 lo halfs. Lanes l16, l16 ^ 1 hold
-    //    neighbouring channels: the even lane stores both hi halfs, the odd lane both lo halfs.
+    //    neighbouring channels: the even lane stores both hi halfs, the odd lane both lo halfs
+    //    (split_pair_word: DPP exchange + one v_perm_b32; range check instead of a silent clamp).
+    //    Element o = rb + 16 (cb16 + nt) + l16 with cb16 = (n0 + wn * WN) / 16: chunk base (o & ~31) floats,
+    //    word (odd ? 16 : 0) + (o & 31) / 2 inside the chunk.
     if (p.out_split.p != nullptr) {
-        char *tbase = reinterpret_cast<char *>(p.out_split.p);
-        const bool odd = l16 & 1;
-        float split_absmax = 0.f;      // range check instead of a silent clamp (ConvParams::ovf)
+        const unsigned psel = split_pair_selector(l16 & 1);
+        char *tlane = reinterpret_cast<char *>(p.out_split.p) + (((l16 & 1) ? 16u : 0u) + ((unsigned)l16 >> 1)) * 4u;
+        const unsigned cb16 = (unsigned)(n0 + wn * WN) >> 4;
+        unsigned range_bits = 0;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned t16 = cb16 + (unsigned)nt;                       // wave-uniform
+            const unsigned coff = ((t16 >> 1) * 32u + (t16 & 1u) * 8u) * 4u;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float g = acc[mt][nt][j];
-                    split_absmax = fmaxf(split_absmax, fabsf(g));
-                    const _Float16 hi = (_Float16)g;
-                    const _Float16 lo = (_Float16)(g - (float)hi);
-                    const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) |
-                                         ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-                    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-                    const unsigned word = odd ? ((oth >> 16) | (own & 0xFFFF0000u)) : ((own & 0xFFFFu) | (oth << 16));
-                    const unsigned o = rb[mt][j] + ncol + nt * 16;
-                    // chunk base (o & ~31) floats = 128 B; word index (odd ? 16 : 0) + (o & 31) / 2
-                    *reinterpret_cast<unsigned *>(tbase + ((o & ~31u) + (odd ? 16u : 0u) + ((o & 31u) >> 1)) * 4u) = word;
-                    if (j == 3) __builtin_amdgcn_sched_barrier(0);
+                    const unsigned word = split_pair_word(acc[mt][nt][j], psel, range_bits);
+                    *reinterpret_cast<unsigned *>(tlane + rb[mt][j] * 4u + coff) = word;
                 }
-        if (p.ovf != nullptr && split_absmax > SPLIT_F16_MAX) *p.ovf = 1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
     }
     // 6. fused GroupNorm statistics of the stored values: fp64 column sums, handed to the producers
     if (p.stats != nullptr) {

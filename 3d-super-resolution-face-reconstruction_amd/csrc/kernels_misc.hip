@@ -786,6 +786,12 @@ __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
         v = __fadd_rn(v, __fmul_rn(z, sa.sigma));
     }
     u.state.p[si] = v;
+    if (u.packed != nullptr) {          // the first conv reads the state as packed split-f16 pixels (kernels_edge.hip)
+        _Float16 *pp = reinterpret_cast<_Float16 *>(u.packed) + u.state.pix(n, y, xx) * 16 + u.xoff + c;
+        const _Float16 hi = (_Float16)v;        // |v| is bounded by the clamp of x0 and the noise: far inside fp16
+        pp[0] = hi;
+        pp[8] = (_Float16)(v - (float)hi);
+    }
     if (sa.frame) sa.frame[i] = v;
 }
 

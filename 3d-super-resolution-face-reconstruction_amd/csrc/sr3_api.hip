@@ -88,6 +88,7 @@ struct Module {
     TDesc rb_out;   // ResBlock output before attention (== out if no attention)
     TDesc act1, act2, h1;   // activated conv inputs and the block1 output (per-shape buffers)
     TDesc up_in;            // M_UP / M_DOWN: split-f16 copy of the raw input (prec 1)
+    int slices_default = 0; // st_out.slices when the generic conv produces the statistics (conv_in_kernel: HW / 256)
     TDesc raw1;             // has_res: un-normalised x ‖ skip in the conv input format (fused res_conv)
     // fused GroupNorm statistics written by the conv that produces out / rb_out / h1 (p == null:
     // the tile does not divide the image, fall back to the statistics kernel)
@@ -112,6 +113,9 @@ struct sr3_ctx {
     GNRef final_gn;
     ConvRef final_conv;
     int mlp_w1 = -1, mlp_b1 = -1, mlp_w2 = -1, mlp_b2 = -1;
+    float *final_wq = nullptr;             // final_conv weights as [9][C][4] for the fused VALU kernel (kernels_edge.hip)
+    float *ci_w = nullptr;                 // downs.0 weights as MFMA fragments for conv_in_kernel (split-f16 mode)
+    float ci_unscale = 1.0f;
     float *nfw = nullptr, *nfb = nullptr;  // concatenated FeatureWiseAffine linears
     int nf_total = 0;
     int in_pad = 0;     // in_channel padded to 32
@@ -131,6 +135,8 @@ struct sr3_ctx {
     uint64_t arena_bytes = 0;
     TDesc x0;                   // [B][H+2][W+2][in_pad]: cond ‖ x ‖ zero pad (UNet input = sampler state)
     TDesc x0s;                  // split-f16 copy of x0 for the first conv (prec 1)
+    float *x0p = nullptr;       // packed split-f16 state for conv_in_kernel (null: shape not supported); kept in
+                                // step with x0 by launch_pack_state / the DDPM update
     TDesc eps;                  // [B][H][W][out_channel]
     TDesc final_act;            // activated input of final_conv
     float *qkvb = nullptr, *aob = nullptr;
@@ -349,6 +355,14 @@ int alloc_weights(sr3_ctx *c) {
     HIP_OK(hipMalloc(&c->nfw, (size_t)c->nf_total * inner * sizeof(float)));
     HIP_OK(hipMalloc(&c->nfb, (size_t)c->nf_total * sizeof(float)));
     c->weight_bytes += (uint64_t)c->nf_total * (inner + 1) * sizeof(float);
+    if (final_conv_supported(c->final_conv.cin, c->final_conv.cout)) {
+        HIP_OK(hipMalloc(&c->final_wq, (size_t)9 * c->final_conv.cin * 4 * sizeof(float)));
+        c->weight_bytes += (uint64_t)9 * c->final_conv.cin * 4 * sizeof(float);
+    }
+    if (c->cfg.in_channel <= 8 && (c->cfg.inner_channel % 32) == 0 && c->cfg.inner_channel <= 64) {
+        HIP_OK(hipMalloc(&c->ci_w, conv_in_weight_floats(c->cfg.inner_channel) * sizeof(float)));
+        c->weight_bytes += conv_in_weight_floats(c->cfg.inner_channel) * sizeof(float);
+    }
     int nf_off = 0;
     for (auto &p : c->params) {
         if (!p.owns) {
@@ -514,6 +528,8 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t o_x0 = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
     const uint64_t o_x0s = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
+    const bool ci_ok = c->ci_w && conv_in_supported(g.in_channel, c->mods[0].conv.cout, H, W);
+    const uint64_t o_x0p = ci_ok ? cv.take((uint64_t)B * (H + 2) * (W + 2) * 8 + 16) : 0;   // + slack: the last A fragment reads one pixel on
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
     const uint64_t o_part = cv.take(max_part);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
@@ -542,6 +558,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             m.st_rb.p = reinterpret_cast<double *>(c->arena + sr_off[i]);
             m.st_h1.p = reinterpret_cast<double *>(c->arena + sh_off[i]);
             m.st_out.slices = m.st_rb.slices = m.st_h1.slices = s_slices[i];
+            m.slices_default = s_slices[i];
             if (!(m.kind == M_RES && m.rb.attn)) m.st_rb = m.st_out;   // rb_out aliases out
             // a conv that runs split-K does not produce fused statistics: the GroupNorm that
             // consumes its output falls back to the statistics kernel
@@ -564,6 +581,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     }
     c->x0 = desc(o_x0, c->in_pad, H, W, 1);
     c->x0s = desc(o_x0s, c->in_pad, H, W, 1);
+    c->x0p = ci_ok ? at(o_x0p) : nullptr;
     c->eps = desc(o_eps, g.out_channel, H, W, 0);
     c->final_act = desc(o_fa, c->final_gn.C, H, W, 1);
     c->qkvb = at(o_qkv); c->aob = at(o_ao);
@@ -707,12 +725,28 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
     const bool so_mode = c->prec && c->all_fused && !c->no_fused_stats && !so_off;
     const int n_pre = c->n_downs + c->n_mid;
     static const bool no_direct = getenv("SR3_NO_TWIN") && atoi(getenv("SR3_NO_TWIN"));   // A/B: raw-concatenation pass
+    static const bool no_edge = getenv("SR3_NO_EDGE") && atoi(getenv("SR3_NO_EDGE"));     // A/B: generic kernels for downs.0 / final_conv
     for (int i = 0; i < (int)c->mods.size(); ++i) {
         Module &m = c->mods[i];
         const bool is_up_path = i >= n_pre;
         switch (m.kind) {
         case M_CONV_IN:
-            if (c->prec) {      // the 6 (of 32 padded) input channels in split-f16 form: the first conv then runs
+            m.st_out.slices = m.slices_default;
+            if (c->prec && c->x0p && !no_edge) {
+                // downs.0 on the packed split-f16 state (kernels_edge.hip): 3 K-steps of 24 live k-values instead
+                // of 9 K-steps of 32 mostly-zero channels, no split copy of the state tensor
+                if (m.st_out.p) m.st_out.slices = H * W / 256;       // one statistics slice per 256-pixel block
+                const bool st = m.st_out.p && !c->no_fused_stats;
+                c->pbegin(F_CONV);
+                launch_conv_in(c->x0p, c->ci_w, m.conv.b >= 0 ? c->params[m.conv.b].dev : nullptr, c->ci_unscale, B, m.out,
+                               m.out_s, !(so_mode && m.out_s.p), st ? const_cast<double *>(m.st_out.p) : nullptr,
+                               m.st_out.slices, c->d_ovf, c->stream);
+                if (c->prof) {
+                    char tag[160];
+                    snprintf(tag, sizeof tag, "conv_in k3 %dx%d cin%d cout%d packed-state mfma16", H, W, m.conv.cin, m.conv.cout);
+                    c->pend(2.0 * (double)B * H * W * m.conv.cout * 9.0 * m.conv.cin, tag);
+                }
+            } else if (c->prec) {   // the 6 (of 32 padded) input channels in split-f16 form: the first conv then runs
                                 // on the fast path too instead of 9 mostly-zero K-steps of f32 MFMA
                 c->pbegin(F_GN);
                 launch_gn_apply_rows(cur, kNone, B, nullptr, nullptr, 0, 1, c->x0s, c->stream, TDesc(), 0, c->d_ovf);
@@ -760,9 +794,29 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
         scur = m.st_out;
         if (i < c->n_downs) feats.push_back(i);
     }
+    if (c->final_wq && !cur_so && !no_edge) {
+        // final_conv (unet.py:229,263): GroupNorm + Swish + Conv3x3(C -> 3) as ONE fp32 VALU kernel behind the
+        // statistics finalize — no activated copy of the 128x128 tensor, no MFMA tile that is 29/32 padding
+        const GNRef &g = c->final_gn;
+        c->pbegin(F_GN);
+        if (scur.p && !c->no_fused_stats)
+            launch_groupnorm_finalize(scur, cur.C, StatsRef(), 0, B, cur.H * cur.W, c->cfg.norm_groups, c->params[g.gamma].dev,
+                                      c->params[g.beta].dev, 1e-5f, c->gscale, c->gshift, c->stream);
+        else
+            launch_groupnorm_affine(cur, kNone, B, c->cfg.norm_groups, c->params[g.gamma].dev, c->params[g.beta].dev, 1e-5f,
+                                    c->gpart, c->gscale, c->gshift, c->stream);
+        c->pend();
+        c->pbegin(F_CONV);
+        launch_final_conv(cur, B, c->gscale, c->gshift, c->final_wq, c->params[c->final_conv.b].dev, c->eps, c->stream);
+        if (c->prof) {
+            char tag[160];
+            snprintf(tag, sizeof tag, "final_conv gn+swish+k3 %dx%d cin%d cout%d fp32-valu", H, W, cur.C, c->final_conv.cout);
+            c->pend(2.0 * (double)B * H * W * c->final_conv.cout * 9.0 * cur.C, tag);
+        }
+        return;
+    }
     run_gn_act(c, cur, kNone, c->final_gn, B, 2, c->final_act, scur, StatsRef());
     run_conv(c, c->final_act, kNone, c->final_conv, B, 1, 0, nullptr, kNone, c->eps, true);
-    (void)H; (void)W;
 }
 
 void run_embed(sr3_ctx *c, const float *nl, int stride, int B) {
@@ -870,6 +924,7 @@ void enqueue_step(sr3_ctx *c) {
     run_unet_body(c, B, H, W);
     UpdateParams u;
     u.state = c->x0; u.C = c->cfg.out_channel;
+    u.packed = c->x0p;          // kept current in both arithmetic modes (the mode may change between steps)
     u.xoff = c->cfg.in_channel - c->cfg.out_channel;
     u.eps = c->eps;
     u.args = c->d_step;
@@ -976,6 +1031,8 @@ void sr3_destroy(sr3_ctx *c) {
         if (p.owns && p.dev) (void)hipFree(p.dev);
         if (p.dev_split) (void)hipFree(p.dev_split);
     }
+    if (c->final_wq) (void)hipFree(c->final_wq);
+    if (c->ci_w) (void)hipFree(c->ci_w);
     if (c->nfw) (void)hipFree(c->nfw);
     if (c->nfb) (void)hipFree(c->nfb);
     if (c->arena) (void)hipFree(c->arena);
@@ -1039,6 +1096,16 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
         // weights may change while earlier launches are still reading them
         HIP_OK(hipStreamSynchronize(c->stream));
         if (p.kind == P_CONV) {
+            if (c->ci_w && &p == &c->params[c->mods[0].conv.w]) {
+                std::vector<float> wf(conv_in_weight_floats(p.cout));
+                c->ci_unscale = pack_conv_in_weight(host, p.cout, p.cin, wf.data());
+                HIP_OK(hipMemcpy(c->ci_w, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            if (c->final_wq && &p == &c->params[c->final_conv.w]) {
+                std::vector<float> wq((size_t)9 * p.cin * 4);
+                pack_final_conv_weight(host, p.cout, p.cin, wq.data());
+                HIP_OK(hipMemcpy(c->final_wq, wq.data(), wq.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             std::vector<float> packed((size_t)p.ks * p.ks * p.cout * p.cin_pad);
             pack_conv_weight(host, p.cout, p.cin, p.ks, p.cin_pad, packed.data());
             size_t rows = (size_t)p.ks * p.ks * p.cout;
@@ -1083,6 +1150,7 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     if (range_reset(c)) return -1;
     c->pbegin(F_MISC);
     launch_nchw_to_nhwc(x_dev, B, c->cfg.in_channel, c->x0, 0, c->stream);
+    if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
     c->pend();
     run_embed(c, noise_level_dev, 1, B);
     run_unet_body(c, B, H, W);
@@ -1136,6 +1204,7 @@ int sr3_sample_begin(sr3_ctx *c, const float *cond_dev, int B, int H, int W, con
     c->pbegin(F_MISC);
     if (cond_dev) launch_nchw_to_nhwc(cond_dev, B, nc, c->x0, 0, c->stream);
     launch_init_state(c->x0, nc, C, init_noise_dev, seed, image_offset, B, c->stream);
+    if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
     c->pend();
     c->sampling = true;
     HIP_OK(hipGetLastError());

@@ -82,6 +82,26 @@ struct ConvParams {
 };
 // largest magnitude the split-f16 format (hi + lo, both fp16) can hold
 constexpr float SPLIT_F16_MAX = 65504.0f;
+
+// ---- split-f16 twin stores from MFMA accumulators (conv epilogues) -----------------------------------
+// Two lanes that hold neighbouring channels (lane ^ 1) exchange halfs so that each lane stores ONE 4-byte
+// word: the even lane both hi halfs, the odd lane both lo halfs. own = hi | lo << 16, oth = the partner's
+// (DPP quad_perm [1,0,3,2]); v_perm_b32 picks {own.hi16?..} by a per-lane selector:
+//   even: [own.b0, own.b1, oth.b0, oth.b1]   odd: [oth.b2, oth.b3, own.b2, own.b3]
+// (v_perm_b32 D = bytes of {src0 = oth : bytes 4..7, src1 = own : bytes 0..3}).
+// range: running unsigned max of (hi bits & 0x7C00) — 0x7C00 at the end means some hi half was inf / nan,
+// i.e. |value| beyond what hi + lo can hold (>= 65520) or not finite: two VALU operations per value.
+__device__ __forceinline__ unsigned split_pair_selector(bool odd) { return odd ? 0x03020706u : 0x05040100u; }
+__device__ __forceinline__ unsigned split_pair_word(float v, unsigned selector, unsigned &range) {
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    const unsigned e = own & 0x7C00u;
+    range = e > range ? e : range;
+    const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    return __builtin_amdgcn_perm(oth, own, selector);
+}
+__device__ __forceinline__ bool split_range_overflow(unsigned range) { return range == 0x7C00u; }
 void launch_conv(const ConvParams &p, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
 // parity (py, px) see only a 2x2 window of the low-resolution input, with the 3x3 taps that land
@@ -171,6 +191,7 @@ struct StepArgs {
     uint64_t seed, image_offset;
 };
 struct UpdateParams {
+    float *packed = nullptr;   // optional packed split-f16 copy of the state (conv_in_kernel): 16 halfs per padded pixel
     TDesc state;        // x lives in channels [xoff, xoff+C)
     int xoff, C;        // C = image channels (3)
     TDesc eps;          // eps.C >= C
@@ -182,6 +203,24 @@ void launch_init_state(const TDesc &state, int xoff, int C, const float *noise, 
                        uint64_t image_offset, int B, hipStream_t s);
 void launch_philox_normal(uint64_t seed, uint64_t image, uint32_t draw, int n, float *out,
                           hipStream_t s);
+
+// ---- edge convolutions (kernels_edge.hip) ----------------------------------------------------------
+// final_conv = GroupNorm affine + Swish + Conv3x3(C -> Cout <= 4) in one fp32 VALU kernel: x is the raw
+// fp32 zero-bordered tensor, scale / shift [B][C] the folded GroupNorm (gn_finalize), wq the weights as
+// [9][C][4] (pack_final_conv_weight), out [B][H][W][Cout] unpadded
+bool final_conv_supported(int C, int Cout);
+void pack_final_conv_weight(const float *oihw, int Cout, int C, float *dst);
+void launch_final_conv(const TDesc &x, int B, const float *scale, const float *shift, const float *wq, const float *bias,
+                       const TDesc &out, hipStream_t s);
+
+// downs.0 (Conv3x3 in_channel <= 8 -> Cout) on the packed split-f16 state: xp = [B][H+2][W+2] pixels of
+// 16 halfs (8 channels hi | lo; + 16 floats of slack behind the last pixel), wci from pack_conv_in_weight
+bool conv_in_supported(int Cin, int Cout, int H, int W);
+float pack_conv_in_weight(const float *oihw, int Cout, int Cin, float *dst_as_float);
+size_t conv_in_weight_floats(int Cout);
+void launch_pack_state(const TDesc &x, int B, float *xp, hipStream_t s, int *ovf);
+void launch_conv_in(const float *xp, const float *wci, const float *bias, float w_unscale, int B, const TDesc &out,
+                    const TDesc &out_split, int out_f32, double *stats, int stats_slices, int *ovf, hipStream_t s);
 
 // ---- pre-processing: PIL-exact 8-bit bicubic resize -> sampler input tensor (kernels_pre.hip) ----
 } // namespace sr3

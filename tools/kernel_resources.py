@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "3d-super-resolution-face-reconstruction_amd", "csrc")
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "kernels_conv.hip"
-    extra = sys.argv[2:]
+    extra = sys.argv[2:] + (["-fno-slp-vectorize"] if src == "kernels_edge.hip" else [])
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
            os.path.join(CSRC, src), "-o", "/tmp/_kres.o", "-Rpass-analysis=kernel-resource-usage", *extra]
     r = subprocess.run(cmd, capture_output=True, text=True)
