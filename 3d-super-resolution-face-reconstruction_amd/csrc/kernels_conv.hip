@@ -789,6 +789,26 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
                         dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
                     });
                 }
+#ifdef SR3_EXPERIMENTS
+                {   // experiment (profiles/README.md, GroupNorm-apply fusion): bits 8..15 = N dummy vector operations per
+                    // K-step in every producer lane (every 8th one a v_exp_f32), the VALU load an in-kernel
+                    // a*x+b / Swish / hi-lo split of the A tile would add next to the f16 MFMAs
+                    // eight independent chains (the real work has that much parallelism: ~17 elements per lane)
+                    const int nv = (p.dbg >> 8) & 0xFF;
+                    float z[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) z[u] = (float)(lane + u);
+                    for (int i = 0; i < nv; i += 8) {
+#pragma unroll
+                        for (int u = 0; u < 7; ++u) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(z[u]) : "v"(1.000001f));
+                        z[7] = __expf(z[7] * 1e-6f);
+                    }
+                    float zs = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) zs += z[u];
+                    if (zs == 1234.5f) rowimg[0] = 1;     // keep the chains alive
+                }
+#endif
                 if (!(SR3_DBG(p) & 8)) producer_sync<0>();          // experiment bit 3: no barriers (timing only)
                 ++k;
             });

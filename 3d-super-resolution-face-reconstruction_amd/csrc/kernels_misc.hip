@@ -3,6 +3,7 @@
 // All fp32, NHWC activations. gfx950 only (64-lane wavefronts).
 #include "sr3_internal.h"
 #include <math.h>
+#include <type_traits>
 
 namespace sr3 {
 
@@ -605,6 +606,307 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 
 } // namespace
 
+// -------------------------------------------------------------------------------------------------
+// Split-f16 form of the same core (precision mode f16x3): q, k, v arrive in the conv's split operand
+// format (the qkv projection writes only the twin of its output: per token 3C/32 chunks of 32 hi
+// halfs | 32 lo halfs), every product is lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_f16 with fp32
+// accumulation, the probabilities are split in LDS after the fp32 softmax. One block = 32 queries of
+// one image; a wave takes 16-key tiles (scores) and 16-channel tiles (P v) round-robin.
+//   A fragments (q rows, P rows): lane (l16, q4) holds row l16, k-chunk q4 = 8 consecutive k;
+//   B fragments of k rows: the same pattern; of v: 8 consecutive KEYS of channel l16 — gathered as
+//   2-byte loads from the 8 key rows (v is stored token-major).
+// Output: fp32 [B][N][C] and / or the split twin of it (input format of the out projection).
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+// v^T in the split format: vt[b][c][Np / 32 chunks][32 hi halfs of keys | 32 lo halfs] from the token-major
+// v part of qkv (one LDS transpose per 32 keys x 128 channels; done once per image, not once per block of
+// queries). Keys >= N are clamped (their probabilities are 0).
+__global__ __launch_bounds__(256) void attention_vt_kernel(const float *__restrict__ qkv, int N, int C,
+                                                           float *__restrict__ vt) {
+    constexpr int VROW = 520;                                   // bytes per staged key row (512 + 8: bank spread)
+    __shared__ __attribute__((aligned(16))) char T[32 * VROW];
+    const int Np = (N + 31) & ~31;
+    const int ks = blockIdx.x, cq = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int nch = C >> 5;
+    const size_t rsb = (size_t)3 * C * 4;
+    const char *base = reinterpret_cast<const char *>(qkv) + (size_t)b * N * rsb;
+    {
+        const int key = min(ks * 32 + (tid >> 3), N - 1);
+        const char *src = base + (size_t)key * rsb + (size_t)(2 * nch + cq * 4) * 128;
+        char *dst = T + (tid >> 3) * VROW + (tid & 7) * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int piece = (tid & 7) * 4 + u;                // 16-B piece of the 512-B row; chunk = piece / 8
+            double2 v = make_double2(0.0, 0.0);
+            if (cq * 4 + (piece >> 3) < nch) v = *reinterpret_cast<const double2 *>(src + piece * 16);
+            *reinterpret_cast<double *>(dst + u * 16) = v.x;   // 8-byte stores: the padded rows are 8-B aligned
+            *reinterpret_cast<double *>(dst + u * 16 + 8) = v.y;
+        }
+    }
+    __syncthreads();
+    const int cw = tid >> 1, hl = tid & 1;                      // channel inside the quarter, hi | lo
+    const int c = cq * 128 + cw;
+    if (c >= C) return;
+    const _Float16 *col = reinterpret_cast<const _Float16 *>(T + (cw >> 5) * 128 + (cw & 31) * 2 + hl * 64);
+    h16x8 o[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[g][j] = col[(g * 8 + j) * (VROW / 2)];
+    char *dst = reinterpret_cast<char *>(vt) + (((size_t)b * C + c) * (Np / 32) + ks) * 128 + hl * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<h16x8 *>(dst + g * 16) = o[g];
+}
+
+// NTW / NTC: key tiles (scores) and channel tiles (P v) per wave, compile-time maxima
+template <int NTW, int NTC>
+__global__ __launch_bounds__(256) void attention_split_kernel(const float *__restrict__ qkv, const float *__restrict__ vt,
+                                                              int N, int C, float *__restrict__ out,
+                                                              float *__restrict__ out_split, int *ovf) {
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [32][ld]: fp32 scores, then P as [hi8|lo8] groups
+    const int Np = (N + 31) & ~31;
+    const int ld = Np + 8;
+    // XCD-aware block order (speed only): blocks b and b + 8 share an XCD, so every XCD gets a contiguous
+    // range of (image, query block) pairs — the query blocks of one image then read its k and v^T through
+    // ONE L2 instead of eight (measured: the kernel was bound by those re-reads)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, loc = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+    }
+    const int nqb = Np / 32;
+    const int b = bid / nqb, q0 = (bid - b * nqb) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l16 = lane & 15, q4 = lane >> 4;
+    const size_t rsb = (size_t)3 * C * 4;                        // bytes per token row
+    const char *base = reinterpret_cast<const char *>(qkv) + (size_t)b * N * rsb;
+    const float sdiv = sqrtf((float)C);
+    const int nch = C >> 5;
+
+    // ---- scores: S[query][key] = q . k / sqrt(C). Wave w owns the key tiles w * NTW .. + NTW - 1: the q
+    // fragments of a channel chunk are loaded once for all of them ----
+    {
+        const char *qrow[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) qrow[mt] = base + (size_t)min(q0 + mt * 16 + l16, N - 1) * rsb + q4 * 16;
+        const int nkt = Np / 16;                                  // key tiles
+        const char *krow[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+            krow[i] = base + (size_t)min((wid * NTW + i) * 16 + l16, N - 1) * rsb + (size_t)nch * 128 + q4 * 16;
+        f32x4a acc[NTW][2];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][mt][r] = 0.f;
+        if (wid * NTW < nkt) {
+            // the fragments of chunk ch + 1 are in flight while chunk ch multiplies (two register sets; rows of
+            // tiles past the end are clamped duplicates whose scores are never stored)
+            h16x8 ah[2][2], al[2][2], bh[2][NTW], bl[2][NTW];
+            auto fetch = [&](auto setc, int ch) {
+                constexpr int set = decltype(setc)::value;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    ah[set][mt] = *reinterpret_cast<const h16x8 *>(qrow[mt] + ch * 128);
+                    al[set][mt] = *reinterpret_cast<const h16x8 *>(qrow[mt] + ch * 128 + 64);
+                }
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    bh[set][i] = *reinterpret_cast<const h16x8 *>(krow[i] + ch * 128);
+                    bl[set][i] = *reinterpret_cast<const h16x8 *>(krow[i] + ch * 128 + 64);
+                }
+            };
+            auto mult = [&](auto setc) {
+                constexpr int set = decltype(setc)::value;
+#pragma unroll
+                for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[set][mt], bh[set][i], acc[i][mt], 0, 0, 0);
+                        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][mt], bl[set][i], acc[i][mt], 0, 0, 0);
+                        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][mt], bh[set][i], acc[i][mt], 0, 0, 0);
+                    }
+            };
+            fetch(std::integral_constant<int, 0>{}, 0);
+            for (int ch = 0; ch < nch; ch += 2) {               // C is a multiple of 32; odd chunk counts re-fetch the last one
+                fetch(std::integral_constant<int, 1>{}, min(ch + 1, nch - 1));
+                mult(std::integral_constant<int, 0>{});
+                if (ch + 1 < nch) {
+                    fetch(std::integral_constant<int, 0>{}, min(ch + 2, nch - 1));
+                    mult(std::integral_constant<int, 1>{});
+                }
+            }
+        }
+        // C/D map: col = l16 (key), row = 4 q4 + j (query)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int kt = wid * NTW + i;
+            if (kt < nkt) {
+                const int col = kt * 16 + l16;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        S[(mt * 16 + 4 * q4 + j) * ld + col] = (col < N) ? acc[i][mt][j] / sdiv : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax over keys (fp32, 8 lanes per query row), then P -> [8 hi halfs | 8 lo halfs] per 8 keys, in place ----
+    {
+        const int row = tid >> 3, sub = tid & 7;
+        float *sr = S + row * ld;
+        float mx = -INFINITY;
+        for (int c = sub; c < Np; c += 8) mx = fmaxf(mx, sr[c]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        mx = fmaxf(mx, __shfl_xor(mx, 4));
+        float sum = 0.f;
+        for (int c = sub; c < Np; c += 8) {
+            const float e = expf(sr[c] - mx);
+            sr[c] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        __syncthreads();                    // every lane of the row has finished its strided pass
+        for (int g = sub; g < Np / 8; g += 8) {
+            float *gp = sr + g * 8;
+            const f32x4a v0 = *reinterpret_cast<const f32x4a *>(gp), v1 = *reinterpret_cast<const f32x4a *>(gp + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            h16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = f[j] / sum;
+                hi[j] = (_Float16)pv;
+                lo[j] = (_Float16)(pv - (float)hi[j]);
+            }
+            *reinterpret_cast<h16x8 *>(gp) = hi;
+            *reinterpret_cast<h16x8 *>(gp + 4) = lo;
+        }
+    }
+    __syncthreads();
+
+    // ---- out = P v: A = P rows from LDS, B = rows of v^T (8 consecutive keys per lane and channel); wave w
+    // owns the channel tiles w, w + 4, ... ----
+    const unsigned psel = split_pair_selector(l16 & 1);
+    unsigned range_bits = 0;
+    const int nct = C >> 4, nks = Np >> 5;
+    const char *vrow[NTC];
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+        const int c = min((wid + 4 * t) * 16 + l16, C - 1);
+        vrow[t] = reinterpret_cast<const char *>(vt) + ((size_t)b * C + c) * nks * 128 + q4 * 16;
+    }
+    f32x4a acc[NTC][2];
+#pragma unroll
+    for (int t = 0; t < NTC; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][mt][r] = 0.f;
+    {
+        // v^T fragments of key step ks + 1 in flight while step ks multiplies (channel tiles past the end are
+        // clamped duplicates that are never stored)
+        h16x8 vh[2][NTC], vl[2][NTC];
+        auto fetch = [&](auto setc, int ks) {
+            constexpr int set = decltype(setc)::value;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) {
+                vh[set][t] = *reinterpret_cast<const h16x8 *>(vrow[t] + ks * 128);
+                vl[set][t] = *reinterpret_cast<const h16x8 *>(vrow[t] + ks * 128 + 64);
+            }
+        };
+        auto mult = [&](auto setc, int ks) {
+            constexpr int set = decltype(setc)::value;
+            h16x8 ah[2], al[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float *pp = S + (mt * 16 + l16) * ld + (ks * 4 + q4) * 8;
+                ah[mt] = *reinterpret_cast<const h16x8 *>(pp);
+                al[mt] = *reinterpret_cast<const h16x8 *>(pp + 4);
+            }
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], vh[set][t], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vl[set][t], acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vh[set][t], acc[t][mt], 0, 0, 0);
+                }
+        };
+        fetch(std::integral_constant<int, 0>{}, 0);
+        for (int ks = 0; ks < nks; ks += 2) {
+            fetch(std::integral_constant<int, 1>{}, min(ks + 1, nks - 1));
+            mult(std::integral_constant<int, 0>{}, ks);
+            if (ks + 1 < nks) {
+                fetch(std::integral_constant<int, 0>{}, min(ks + 2, nks - 1));
+                mult(std::integral_constant<int, 1>{}, ks + 1);
+            }
+        }
+    }
+    // C/D map: col = l16 (channel), row = 4 q4 + j (query)
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+        const int ch0 = (wid + 4 * t) * 16;
+        if (wid + 4 * t < nct) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = q0 + mt * 16 + 4 * q4 + j;
+                    const bool ok = row < N;
+                    const size_t o = ((size_t)b * N + (ok ? row : 0)) * C + ch0 + l16;
+                    if (out != nullptr && ok) out[o] = acc[t][mt][j];
+                    if (out_split != nullptr) {
+                        // every lane takes part in the DPP exchange; only rows of the image are stored
+                        const unsigned word = split_pair_word(acc[t][mt][j], psel, range_bits);
+                        if (ok) reinterpret_cast<unsigned *>(out_split)[(o & ~(size_t)31) + ((l16 & 1) ? 16 : 0) + ((o & 31) >> 1)] = word;
+                    }
+                }
+        }
+    }
+    if (ovf != nullptr && split_range_overflow(range_bits)) *ovf = 1;
+}
+
+} // namespace
+
+bool attention_split_supported(int N, int C) { return N <= 512 && C <= 512 && (C % 32) == 0; }
+size_t attention_vt_floats(int B, int N, int C) { return (size_t)B * C * ((N + 31) & ~31); }
+
+// qkv_split: [B][N][3C] in the split operand format; vt: scratch of attention_vt_floats(B, N, C) floats;
+// out (fp32) and / or out_split ([B][N][C] split) may be null
+double launch_attention_split(const float *qkv_split, float *vt, int B, int N, int C, float *out, float *out_split,
+                              int *ovf, hipStream_t s) {
+    const int Np = (N + 31) & ~31;
+    hipLaunchKernelGGL(attention_vt_kernel, dim3(Np / 32, (C + 127) / 128, B), dim3(256), 0, s, qkv_split, N, C, vt);
+    const size_t lds = (size_t)32 * (Np + 8) * sizeof(float);
+    const int ntw = (Np / 16 + 3) / 4, ntc = (C / 16 + 3) / 4;
+#define SR3_AT(A, B_)                                                                                              \
+    {                                                                                                              \
+        static size_t attr = 0;                                                                                    \
+        if (lds > attr) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<A, B_>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+            attr = lds;                                                                                            \
+        }                                                                                                          \
+        hipLaunchKernelGGL((attention_split_kernel<A, B_>), dim3((Np / 32) * B), dim3(256), lds, s, qkv_split, vt, N, C, out, \
+                           out_split, ovf);                                                                        \
+    }
+    if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2)
+    else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8)
+    else SR3_AT(8, 8)
+#undef SR3_AT
+    return 4.0 * (double)B * N * N * C;
+}
+
 double launch_attention(const float *qkv, int B, int N, int C, float *out, hipStream_t s) {
     const int Np = (N + 31) & ~31;
     const size_t lds = (size_t)32 * (Np + 4) * sizeof(float);
@@ -659,10 +961,14 @@ __global__ __launch_bounds__(256) void noise_embed_kernel(const EmbedParams p) {
             a = fmaf(ww.x, vv.x, a); a = fmaf(ww.y, vv.y, a); a = fmaf(ww.z, vv.z, a); a = fmaf(ww.w, vv.w, a);
         }
         te[j] = a;
-        if (p.temb) p.temb[(size_t)n * dim + j] = a;
+        if (p.temb && blockIdx.y == 0) p.temb[(size_t)n * dim + j] = a;
     }
     __syncthreads();
-    for (int j = t; j < p.total; j += blockDim.x) {
+    // the FeatureWiseAffine outputs are spread over blockIdx.y (every block recomputes the tiny MLP above:
+    // one block per image left all 7360 dot products of the yml UNet to 256 threads, 86 us per step)
+    const int per = (p.total + gridDim.y - 1) / gridDim.y;
+    const int j0 = blockIdx.y * per, j1 = min(p.total, j0 + per);
+    for (int j = j0 + t; j < j1; j += blockDim.x) {
         float a = p.nfb[j];
         const float4 *w = reinterpret_cast<const float4 *>(p.nfw + (size_t)j * dim);
         const float4 *v = reinterpret_cast<const float4 *>(te);
@@ -678,7 +984,8 @@ __global__ __launch_bounds__(256) void noise_embed_kernel(const EmbedParams p) {
 
 void launch_noise_embed(const EmbedParams &p, int B, hipStream_t s) {
     const size_t lds = (size_t)(6 * p.dim) * sizeof(float);
-    hipLaunchKernelGGL(noise_embed_kernel, dim3(B), dim3(256), lds, s, p);
+    const int slices = p.total > 0 ? (p.total + 255) / 256 : 1;
+    hipLaunchKernelGGL(noise_embed_kernel, dim3(B, slices), dim3(256), lds, s, p);
 }
 
 // =================================================================================================
@@ -764,6 +1071,8 @@ __global__ void init_state_kernel(const TDesc state, int xoff, int C, const floa
 
 // One p_sample tail (reference diffusion.py:144-151 predict_start_from_noise, :175-176 clamp,
 // :153-162 q_posterior, :182-187 p_sample), element-wise in the reference's operation order.
+// One thread per (image, channel, pixel) in NCHW order (a thread per pixel with its three Philox / Box-Muller
+// evaluations in sequence measured 1.5x slower: the kernel is bound by that arithmetic, not by its accesses).
 __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW, NCHW order
     if (i >= total) return;
@@ -774,7 +1083,8 @@ __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     const int n = (int)(nc / u.C);
     const int c = (int)(nc - (size_t)n * u.C);
     const int y = pp / u.state.W, xx = pp - y * u.state.W;
-    const size_t si = u.state.pix(n, y, xx) * u.state.C + u.xoff + c;
+    const size_t pix = u.state.pix(n, y, xx);
+    const size_t si = pix * u.state.C + u.xoff + c;
     const float x = u.state.p[si];
     const float e = u.eps.p[u.eps.pix(n, y, xx) * u.eps.C + c];
     float x0 = __fsub_rn(__fmul_rn(sa.a, x), __fmul_rn(sa.b, e));
@@ -787,10 +1097,10 @@ __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     }
     u.state.p[si] = v;
     if (u.packed != nullptr) {          // the first conv reads the state as packed split-f16 pixels (kernels_edge.hip)
-        _Float16 *pp = reinterpret_cast<_Float16 *>(u.packed) + u.state.pix(n, y, xx) * 16 + u.xoff + c;
+        _Float16 *pk = reinterpret_cast<_Float16 *>(u.packed) + pix * 16 + u.xoff + c;
         const _Float16 hi = (_Float16)v;        // |v| is bounded by the clamp of x0 and the noise: far inside fp16
-        pp[0] = hi;
-        pp[8] = (_Float16)(v - (float)hi);
+        pk[0] = hi;
+        pk[8] = (_Float16)(v - (float)hi);
     }
     if (sa.frame) sa.frame[i] = v;
 }

@@ -139,7 +139,7 @@ struct sr3_ctx {
                                 // step with x0 by launch_pack_state / the DDPM update
     TDesc eps;                  // [B][H][W][out_channel]
     TDesc final_act;            // activated input of final_conv
-    float *qkvb = nullptr, *aob = nullptr;
+    float *qkvb = nullptr, *aob = nullptr, *vtb = nullptr;   // attention: qkv, core output, v^T scratch (split-f16 core)
     float *part = nullptr;      // split-K partial sums (small-M convs)
     float *gscale = nullptr, *gshift = nullptr, *gpart = nullptr;
     float *temb = nullptr, *cbias = nullptr;
@@ -446,7 +446,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         twin[i] = skip || (nx && (nx->kind == M_DOWN || nx->kind == M_UP || (nx->kind == M_RES && nx->rb.has_res)));
     }
     std::vector<int> s_slices(nm, 0);
-    uint64_t max_qkv = 0, max_ao = 0, max_part = 0;
+    uint64_t max_qkv = 0, max_ao = 0, max_part = 0, max_vt = 0;
     int h = H, w = W;
     int cur_c = c->in_pad;
     std::vector<int> feat_c;
@@ -466,6 +466,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
                 const uint64_t nu = (uint64_t)B * h * w * oc;
                 if (3 * nu > max_qkv) max_qkv = 3 * nu;
                 if (nu > max_ao) max_ao = nu;
+                max_vt = std::max<uint64_t>(max_vt, attention_vt_floats(B, h * w, oc));
                 if ((long)h * w > 1024) return fail("attention over %d tokens exceeds the 1024-token LDS tile", h * w);
             }
         }
@@ -530,7 +531,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t o_x0s = cv.take((uint64_t)B * (H + 2) * (W + 2) * c->in_pad);
     const bool ci_ok = c->ci_w && conv_in_supported(g.in_channel, c->mods[0].conv.cout, H, W);
     const uint64_t o_x0p = ci_ok ? cv.take((uint64_t)B * (H + 2) * (W + 2) * 8 + 16) : 0;   // + slack: the last A fragment reads one pixel on
-    const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao);
+    const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao), o_vt = cv.take(max_vt);
     const uint64_t o_part = cv.take(max_part);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
     const uint64_t o_gp = cv.take(gn_workspace_floats(B, c->c_max));
@@ -584,7 +585,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     c->x0p = ci_ok ? at(o_x0p) : nullptr;
     c->eps = desc(o_eps, g.out_channel, H, W, 0);
     c->final_act = desc(o_fa, c->final_gn.C, H, W, 1);
-    c->qkvb = at(o_qkv); c->aob = at(o_ao);
+    c->qkvb = at(o_qkv); c->aob = at(o_ao); c->vtb = at(o_vt);
     c->part = max_part ? at(o_part) : nullptr;
     c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
     c->temb = at(o_te); c->cbias = at(o_cb);
@@ -703,12 +704,26 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
-        run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv, true);
-        c->pbegin(F_ATTN);
-        const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
-        c->pend(fl);
-        run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out, false, kNone,
-                 nullptr, nullptr, m.st_out, m.out_s);
+        static const bool attn_f32 = getenv("SR3_ATTN_F32") && atoi(getenv("SR3_ATTN_F32"));   // A/B: f32-MFMA core in f16x3 mode
+        if (c->prec && !attn_f32 && attention_split_supported(h * w, rb.cout)) {
+            // split-f16 mode: the qkv projection writes ONLY the split twin of its output, the attention core
+            // multiplies hi/lo halfs (3 x v_mfma_f32_16x16x32_f16 per product) and hands its result to the out
+            // projection in the same format
+            run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv, true, kNone, nullptr, nullptr, StatsRef(), qkv,
+                     kNone, false);
+            c->pbegin(F_ATTN);
+            const double fl = launch_attention_split(c->qkvb, c->vtb, B, h * w, rb.cout, nullptr, c->aob, c->d_ovf, c->stream);
+            c->pend(fl);
+            run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out, true, kNone,
+                     nullptr, nullptr, m.st_out, m.out_s);
+        } else {
+            run_conv(c, m.act2, kNone, rb.qkv, B, 1, 0, nullptr, kNone, qkv, true);
+            c->pbegin(F_ATTN);
+            const double fl = launch_attention(c->qkvb, B, h * w, rb.cout, c->aob, c->stream);
+            c->pend(fl);
+            run_conv(c, unpadded(c->aob, rb.cout, h, w), kNone, rb.aout, B, 1, 0, nullptr, m.rb_out, m.out, false, kNone,
+                     nullptr, nullptr, m.st_out, m.out_s);
+        }
     }
 }
 
@@ -1449,6 +1464,19 @@ int sr3_op_attention(sr3_ctx *c, const float *qkv_dev, int B, int N, int C, floa
     if (!c || !qkv_dev || !out_dev) return fail("sr3_op_attention: null argument");
     if (C % 32 || N < 1 || N > 1024) return fail("sr3_op_attention: need C %% 32 == 0 and 1 <= N <= 1024");
     HIP_OK(hipSetDevice(c->device));
+    if (c->prec && attention_split_supported(N, C)) {
+        // split-f16 mode: the engine's own sequence — q, k, v in the split operand format, fp32 result
+        float *tmp = nullptr;
+        HIP_OK(hipMalloc(&tmp, ((size_t)B * N * 3 * C + attention_vt_floats(B, N, C)) * sizeof(float)));
+        if (range_reset(c)) return -1;
+        const TDesc src = unpadded(const_cast<float *>(qkv_dev), 3 * C, N, 1), dst = unpadded(tmp, 3 * C, N, 1);
+        launch_gn_apply_rows(src, kNone, B, nullptr, nullptr, 0, 1, dst, c->stream, TDesc(), 0, c->d_ovf);
+        launch_attention_split(tmp, tmp + (size_t)B * N * 3 * C, B, N, C, out_dev, nullptr, c->d_ovf, c->stream);
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipFree(tmp));
+        HIP_OK(hipGetLastError());
+        return range_check(c, "sr3_op_attention");
+    }
     launch_attention(qkv_dev, B, N, C, out_dev, c->stream);
     HIP_OK(hipGetLastError());
     return 0;

@@ -160,6 +160,12 @@ float split_conv_weight_k(const float *packed, size_t rows, int CinPad, int k, f
 
 // ---- attention core ----------------------------------------------------------------------------
 double launch_attention(const float *qkv, int B, int N, int C, float *out, hipStream_t s);
+// split-f16 form: qkv in the conv's split operand format ([B][N][3C], 32-channel chunks of hi | lo halfs);
+// out (fp32 [B][N][C]) and / or out_split (the same tensor in the split format) may be null
+bool attention_split_supported(int N, int C);
+size_t attention_vt_floats(int B, int N, int C);     // scratch for v^T
+double launch_attention_split(const float *qkv_split, float *vt, int B, int N, int C, float *out, float *out_split,
+                              int *ovf, hipStream_t s);
 
 // ---- noise-level embedding ---------------------------------------------------------------------
 struct EmbedParams {

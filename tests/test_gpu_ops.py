@@ -119,11 +119,18 @@ def test_groupnorm_affine(eng, shape):
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=0)
 
 
-@pytest.mark.parametrize("B,N,C", [(2, 64, 512), (1, 256, 512), (3, 1, 64), (2, 4, 32), (2, 100, 64), (1, 16, 512)])
-def test_attention(eng, B, N, C):
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("B,N,C", [(2, 64, 512), (1, 256, 512), (3, 1, 64), (2, 4, 32), (2, 100, 64), (1, 16, 512),
+                                   (3, 256, 64), (1, 1024, 32)])
+def test_attention(eng, B, N, C, prec):
+    """f32: f32-MFMA core; f16x3: the split-f16 core (q, k, v and the probabilities as hi + lo halfs)."""
     rs = np.random.RandomState(B * 1000 + N + C)
     qkv = _rand(rs, B, N, 3 * C)
-    got = eng.op_attention(qkv)
+    eng.set_precision(prec)
+    try:
+        got = eng.op_attention(qkv)
+    finally:
+        eng.set_precision("f32")
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     s = np.einsum("bpc,bqc->bpq", q, k).astype(np.float64) / np.sqrt(C)
     s = np.exp(s - s.max(-1, keepdims=True))
@@ -139,6 +146,12 @@ def test_attention_peaked_softmax(eng):
     qkv[0, 5, :C] *= 40.0
     qkv[0, 7, :C] = 0.0
     got = eng.op_attention(qkv)
+    eng.set_precision("f16x3")
+    try:
+        got16 = eng.op_attention(qkv)
+    finally:
+        eng.set_precision("f32")
+    assert np.abs(got16 - got).max() < 5e-5
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     s = np.einsum("bpc,bqc->bpq", q, k).astype(np.float64) / np.sqrt(C)
     s = np.exp(s - s.max(-1, keepdims=True))
