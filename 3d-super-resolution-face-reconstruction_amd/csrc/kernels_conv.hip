@@ -1139,36 +1139,78 @@ void launch_cfg(const ConvParams &p, hipStream_t s) {
 // Preconditions (checked by the callers in sr3_api.hip): channels multiples of 32, 3x3 inputs
 // zero-bordered (pad 1), up2 only with ks 3 / stride 1 / single input, every tensor < 4 GiB
 // (32-bit byte offsets in the DMA addressing).
-// split-K second pass: out = sum_s part[s] + bias + FeatureWiseAffine bias + residual
-__global__ void conv_splitk_reduce_kernel(const ConvParams p_in, int M, int HWo) {
+// split-K second pass: out = sum_s part[s] + bias + FeatureWiseAffine bias + residual, plus the fused
+// GroupNorm statistics of the result (a split conv cannot produce them itself: its blocks hold partial
+// sums). One block = TP consecutive pixels of one image x all channels: thread (pixel lane, channel quad)
+// walks the pixels of its lane; per-channel fp64 sums go through LDS to one statistics slice per block
+// (ConvParams::stats layout, stats_slices = splitk_stats_slices(HWo) per phase).
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p_in, int M, int HWo, int TP) {
+    __shared__ double2 red[256][4];
     const ConvParams p = phase_params(p_in, blockIdx.y);
-    const int Cout = p.out.C, C4 = Cout >> 2;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)M * C4) return;
-    const int m = (int)(i / C4), n = (int)(i - (size_t)m * C4) << 2;
-    float4 a = *reinterpret_cast<const float4 *>(p.part + (size_t)m * Cout + n);
-    for (int s = 1; s < p.splits; ++s) {
-        const float4 b = *reinterpret_cast<const float4 *>(p.part + ((size_t)s * M + m) * Cout + n);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    const int img = m / HWo, rem = m - img * HWo, oy = rem / p.Wout;
-    const size_t o = p.out.pix(img, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox) * Cout + n;
-    float v[4] = {a.x, a.y, a.z, a.w};
+    const int Cout = p.out.C, cq = Cout >> 2;
+    const int cqs = min(cq, 256), lanes_p = 256 / cqs;
+    const int t = threadIdx.x, pl = t / cqs;
+    const int m_lo = blockIdx.x * TP;
+    const int img = m_lo / HWo;
+    double st1[4] = {0, 0, 0, 0}, st2[4] = {0, 0, 0, 0};
+    unsigned range_bits = 0;
+    for (int qb = t - pl * cqs; qb < cq && pl < lanes_p; qb += cqs) {     // one pass unless Cout > 1024
+        const int n = qb << 2;
+        for (int pp = pl; pp < TP; pp += lanes_p) {
+            const int m = m_lo + pp;
+            if (m >= M) break;
+            float4 a = *reinterpret_cast<const float4 *>(p.part + (size_t)m * Cout + n);
+            for (int s = 1; s < p.splits; ++s) {
+                const float4 b = *reinterpret_cast<const float4 *>(p.part + ((size_t)s * M + m) * Cout + n);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            const int rem = m - img * HWo, oy = rem / p.Wout;
+            const size_t o = p.out.pix(img, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox) * Cout + n;
+            float v[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (p.bias) v[j] += p.bias[n + j];
-        if (p.chan_bias) v[j] += p.chan_bias[(size_t)img * p.chan_bias_stride + n + j];
-        if (p.resid.p) v[j] += p.resid_split ? load_split(p.resid.p, (unsigned)(o + j)) : p.resid.p[o + j];
-        if (p.out_f32) p.out.p[o + j] = v[j];
-        if (p.out_split.p != nullptr) {
-            const float g = v[j];
-            if (p.ovf != nullptr && fabsf(g) > SPLIT_F16_MAX) *p.ovf = 1;     // detected, not clamped
-            const _Float16 hi = (_Float16)g;
-            _Float16 *hd = reinterpret_cast<_Float16 *>(p.out_split.p + ((o + j) & ~(size_t)31)) + ((o + j) & 31);
-            hd[0] = hi;
-            hd[32] = (_Float16)(g - (float)hi);
+            for (int j = 0; j < 4; ++j) {
+                if (p.bias) v[j] += p.bias[n + j];
+                if (p.chan_bias) v[j] += p.chan_bias[(size_t)img * p.chan_bias_stride + n + j];
+                if (p.resid.p) v[j] += p.resid_split ? load_split(p.resid.p, (unsigned)(o + j)) : p.resid.p[o + j];
+                if (p.out_f32) p.out.p[o + j] = v[j];
+                if (p.out_split.p != nullptr) {
+                    const _Float16 hi = (_Float16)v[j];         // detected, not clamped (range_bits)
+                    const unsigned e = (unsigned)__builtin_bit_cast(unsigned short, hi) & 0x7C00u;
+                    range_bits = e > range_bits ? e : range_bits;
+                    _Float16 *hd = reinterpret_cast<_Float16 *>(p.out_split.p + ((o + j) & ~(size_t)31)) + ((o + j) & 31);
+                    hd[0] = hi;
+                    hd[32] = (_Float16)(v[j] - (float)hi);
+                }
+                st1[j] += (double)v[j];
+                st2[j] = fma((double)v[j], (double)v[j], st2[j]);
+            }
+        }
+        if (p.stats != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[t][j] = make_double2(st1[j], st2[j]);
         }
     }
+    if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
+    if (p.stats != nullptr && cq <= 256) {
+        __syncthreads();
+        // thread (channel quad q, j) adds the pixel lanes of channel 4q + j
+        for (int i = t; i < cq * 4; i += 256) {
+            const int q = i >> 2, j = i & 3;
+            double sa = 0, sb = 0;
+            for (int l = 0; l < lanes_p; ++l) { const double2 v = red[l * cqs + q][j]; sa += v.x; sb += v.y; }
+            const int slice = p.stats_slice0 + (m_lo - img * HWo) / TP;
+            double *o = p.stats + (((size_t)img * p.stats_slices + slice) * Cout + i) * 2;
+            o[0] = sa; o[1] = sb;
+        }
+    }
+}
+
+// pixels per block of the split-K reduce (at most 64 statistics slices per image and phase)
+int splitk_reduce_tp(int HWo) { const int tp = HWo / 64; return tp < 1 ? 1 : tp; }
+// 0: the reduce pass cannot produce the statistics of this shape (the caller's statistics kernel runs)
+int splitk_stats_slices(int HWo, int Cout) {
+    const int tp = splitk_reduce_tp(HWo);
+    return ((HWo % tp) == 0 && Cout <= 1024 && (Cout & 3) == 0) ? HWo / tp : 0;
 }
 
 // tile choice: 0 = 128x32, 1 = 128x64, 2 = 64x64, 3 = 128x128
@@ -1211,7 +1253,14 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         p.w_shift = lg(p.Wout);
     }
     if (p.part == nullptr) p.splits = 1;
-    if (p.splits > 1) p.stats = nullptr;   // the caller falls back to the statistics kernel
+    // split-K: the blocks hold partial sums, the statistics come out of the reduce pass (one slice per TP pixels);
+    // they need whole tiles per image and at most 1024 channels, else the caller's statistics kernel runs
+    double *reduce_stats = nullptr;
+    if (p.splits > 1) {
+        const int HWo = p.Hout * p.Wout;
+        if (p.stats && splitk_stats_slices(HWo, p.out.C) > 0) reduce_stats = p.stats;
+        p.stats = nullptr;
+    }
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
@@ -1231,9 +1280,11 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         break;
     }
     if (p.splits > 1) {
-        const size_t items = (size_t)M * (p.out.C >> 2);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256), p.phases), dim3(256), 0, s, p,
-                           (int)M, p.Hout * p.Wout);
+        const int HWo = p.Hout * p.Wout, TP = splitk_reduce_tp(HWo);
+        p.stats = reduce_stats;
+        if (reduce_stats) p.phase_slices = splitk_stats_slices(HWo, p.out.C);   // slices of one sub-pixel phase (phases > 1)
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((M + TP - 1) / TP), p.phases), dim3(256), 0, s, p,
+                           (int)M, HWo, TP);
     }
 }
 

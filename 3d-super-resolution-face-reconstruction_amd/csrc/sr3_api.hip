@@ -445,7 +445,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         const Module *nx = i + 1 < nm ? &c->mods[i + 1] : nullptr;
         twin[i] = skip || (nx && (nx->kind == M_DOWN || nx->kind == M_UP || (nx->kind == M_RES && nx->rb.has_res)));
     }
-    std::vector<int> s_slices(nm, 0);
+    std::vector<int> s_slices(nm, 0), s_out(nm, 0), s_h1(nm, 0);
     uint64_t max_qkv = 0, max_ao = 0, max_part = 0, max_vt = 0;
     int h = H, w = W;
     int cur_c = c->in_pad;
@@ -488,12 +488,19 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
                 want(oc, m.conv.cin_pad);
             }
         }
-        {   // fused statistics: every conv writing an [oc, h, w] tensor uses the same tile height
+        {   // fused statistics: a conv writing an [oc, h, w] tensor leaves one slice per M-tile of an image (every
+            // such conv uses the same tile height), a split-K conv one slice per block of its reduce pass
             const bool up = m.kind == M_UP;                   // 4 phases, each tiled over the low-res image
             const int hw = up ? (h * w) / 4 : h * w;
             const int bm = conv_tile_m((long)B * hw, oc);
-            if (hw % bm == 0) {
-                s_slices[i] = (up ? 4 : 1) * (hw / bm);
+            auto slices_for = [&](int cin) {
+                if (conv_splits((long)B * hw, oc, cin) > 1) return (up ? 4 : 1) * splitk_stats_slices(hw, oc);
+                return (hw % bm == 0) ? (up ? 4 : 1) * (hw / bm) : 0;
+            };
+            s_out[i] = slices_for(m.kind == M_RES ? oc : m.conv.cin_pad);
+            s_h1[i] = m.kind == M_RES ? slices_for(m.rb.cin) : 0;
+            s_slices[i] = std::max(s_out[i], s_h1[i]);
+            if (s_slices[i]) {
                 const uint64_t sf = (uint64_t)B * s_slices[i] * oc * 4;   // 2 doubles per channel
                 so_off[i] = cv.take(sf);
                 sr_off[i] = cv.take(sf);
@@ -558,18 +565,12 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             m.st_out.p = reinterpret_cast<double *>(c->arena + so_off[i]);
             m.st_rb.p = reinterpret_cast<double *>(c->arena + sr_off[i]);
             m.st_h1.p = reinterpret_cast<double *>(c->arena + sh_off[i]);
-            m.st_out.slices = m.st_rb.slices = m.st_h1.slices = s_slices[i];
-            m.slices_default = s_slices[i];
+            m.st_out.slices = m.st_rb.slices = s_out[i];
+            m.st_h1.slices = s_h1[i];
+            m.slices_default = s_out[i];
+            if (!s_out[i]) m.st_out = m.st_rb = StatsRef();      // shape without fused statistics: the statistics kernel runs
+            if (!s_h1[i]) m.st_h1 = StatsRef();
             if (!(m.kind == M_RES && m.rb.attn)) m.st_rb = m.st_out;   // rb_out aliases out
-            // a conv that runs split-K does not produce fused statistics: the GroupNorm that
-            // consumes its output falls back to the statistics kernel
-            const long Mo = (long)B * m.oh * m.ow;
-            if (m.kind == M_RES) {
-                if (conv_splits(Mo, m.oc, m.rb.cin) > 1) m.st_h1 = StatsRef();
-                if (conv_splits(Mo, m.oc, m.oc) > 1) { m.st_rb = StatsRef(); m.st_out = StatsRef(); }
-            } else if (conv_splits(m.kind == M_UP ? Mo / 4 : Mo, m.oc, m.conv.cin_pad) > 1) {
-                m.st_out = StatsRef();
-            }
         }
         if (!m.st_out.p || (m.kind == M_RES && (!m.st_h1.p || !m.st_rb.p))) all_fused = false;
         if (m.kind == M_UP || m.kind == M_DOWN) m.up_in = desc(a1_off[i], m.conv.cin, (int)(a2_off[i] >> 16), (int)(a2_off[i] & 65535), 1);

@@ -116,6 +116,10 @@ void make_up2_phase_weights(const float *packed9, int Cout, int CinPad, float *d
 int conv_tile_m(long M, int Cout);
 // number of K-splits launch_conv wants for this problem (1 = none); Cin per tap, multiple of 32
 int conv_splits(long M, int Cout, int Cin);
+// a split conv's fused GroupNorm statistics come out of its reduce pass: slices per image (and per
+// sub-pixel phase) for an output of HWo pixels; the caller sizes / strides ConvParams::stats with it
+// (0: not available for this shape)
+int splitk_stats_slices(int HWo, int Cout);
 // host helper: OIHW -> [tap][Cout][CinPad] (zero pad input channels up to CinPad)
 void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, float *dst);
 // host helper: fp32 packed weights -> split-f16 layout (same byte size), returns the unscale factor

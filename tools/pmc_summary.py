@@ -18,6 +18,7 @@ from collections import defaultdict
 
 def family(name):
     for key, fam in (("conv_igemm", "conv_igemm"), ("conv3x3_halo", "conv_igemm"), ("conv_splitk", "conv_igemm"),
+                     ("conv_in_kernel", "conv_igemm"), ("final_conv", "conv_igemm"),
                      ("gn_partial", "gn_stats"), ("gn_finalize", "gn_stats"),
                      ("gn_apply", "gn_apply"), ("attention", "attention"), ("noise_embed", "embed"),
                      ("ddpm_update", "update")):

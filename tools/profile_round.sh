@@ -8,7 +8,7 @@ PREC=${1:-f16x3}
 OUT=gpurun_out/prof_$PREC
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="bench.py --steps 5 --warmup 1 --no-alt --no-cpu-baseline --precision $PREC"
+ARGS="bench.py --steps 5 --warmup 1 --no-alt --no-cpu-baseline --no-full-loop --precision $PREC"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_stats -- python3 $ARGS > $OUT/stats.log 2>&1
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/p_fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
