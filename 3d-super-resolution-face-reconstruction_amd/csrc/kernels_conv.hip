@@ -689,6 +689,9 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
 
     if (wid >= 4) {
         // ------------------------------- producer waves -------------------------------------
+#if defined(SR3_CONV_VARIANT) && SR3_CONV_VARIANT == 3
+        __builtin_amdgcn_s_setprio(1);      // experiment: the DMA waves win issue arbitration
+#endif
         const int w = wid - 4;
         const int tid = threadIdx.x - 256;
         if (tid < BM) {
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_h
 #ifndef SR3_CONV_VARIANT
 #define SR3_CONV_VARIANT 1
 #endif
-#if SR3_CONV_VARIANT >= 2
+#if SR3_CONV_VARIANT == 2
         __builtin_amdgcn_s_setprio(1);      // consumers win issue arbitration against the DMA waves
 #endif
         const float *aptr_h[MT], *aptr_l[MT];   // variant >= 1: fragment addresses of the NEXT K-step, computed early
