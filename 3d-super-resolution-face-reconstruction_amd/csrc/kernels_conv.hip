@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // MS: MFMA shape of the consumers, 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16: same
 // FLOP per cycle, but the chip holds a higher clock on it under load — MI355X_MICROARCH.md, DVFS (7))
 template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
-__global__ __launch_bounds__(512, (BN == 64 && MS == 16) ? 6 : 4) void conv3x3_halo_h3(const ConvParams p_in) {
+__global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) void conv3x3_halo_h3(const ConvParams p_in) {
     const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -1162,9 +1162,20 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
         for (int pp = pl; pp < TP; pp += lanes_p) {
             const int m = m_lo + pp;
             if (m >= M) break;
-            float4 a = *reinterpret_cast<const float4 *>(p.part + (size_t)m * Cout + n);
-            for (int s = 1; s < p.splits; ++s) {
-                const float4 b = *reinterpret_cast<const float4 *>(p.part + ((size_t)s * M + m) * Cout + n);
+            // four partials in flight per thread (a plain loop waits for each load); summed in split order
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *pm = p.part + (size_t)m * Cout + n;
+            const size_t sstride = (size_t)M * Cout;
+            int sp = 0;
+            for (; sp + 3 < p.splits; sp += 4) {
+                float4 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const float4 *>(pm + (size_t)(sp + u) * sstride);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+            }
+            for (; sp < p.splits; ++sp) {
+                const float4 b = *reinterpret_cast<const float4 *>(pm + (size_t)sp * sstride);
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
             const int rem = m - img * HWo, oy = rem / p.Wout;
@@ -1233,6 +1244,9 @@ int conv_tile_m(long M, int Cout) { return conv_tile_choice(M, Cout) == 2 ? 64 :
 int conv_splits(long M, int Cout, int Cin) {
     static const int off = getenv("SR3_NO_SPLITK") ? atoi(getenv("SR3_NO_SPLITK")) : 0;
     if (off || (Cout & 3)) return 1;
+#ifdef SR3_EXPERIMENTS
+    if (const char *f = getenv("SR3_FORCE_SPLITS")) return atoi(f);
+#endif
     static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
     const int t = conv_tile_choice(M, Cout);
     const long tiles = ((M + bm[t] - 1) / bm[t]) * ((Cout + bn[t] - 1) / bn[t]);

@@ -3,6 +3,7 @@
 // All fp32, NHWC activations. gfx950 only (64-lane wavefronts).
 #include "sr3_internal.h"
 #include <math.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
 
@@ -107,7 +108,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
                 const bool first = c < C0;
                 const double *pp = first ? part0 : part1;
                 const int Cs = first ? C0 : C1, cl = first ? c : c - C0, sl = first ? slices0 : slices1;
-                for (int s = sl0; s < sl; s += lanes) {
+                // four loads in flight per thread (a plain loop waits for each one); summed in slice order
+                int s = sl0;
+                for (; s + 3 * lanes < sl; s += 4 * lanes) {
+                    double2 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = *reinterpret_cast<const double2 *>(pp + (((size_t)n * sl + s + u * lanes) * Cs + cl) * 2);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a += v[u].x; b += v[u].y; }
+                }
+                for (; s < sl; s += lanes) {
                     const double *o = pp + (((size_t)n * sl + s) * Cs + cl) * 2;
                     a += o[0]; b += o[1];
                 }
@@ -694,8 +705,11 @@ __global__ __launch_bounds__(256) void attention_vt_kernel(const float *__restri
 template <int NTW, int NTC>
 __global__ __launch_bounds__(256) void attention_split_kernel(const float *__restrict__ qkv, const float *__restrict__ vt,
                                                               int N, int C, float *__restrict__ out,
-                                                              float *__restrict__ out_split, int *ovf) {
+                                                              float *__restrict__ out_split, int *ovf, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float S[];   // [32][ld]: fp32 scores, then P as [hi8|lo8] groups
+#ifndef SR3_EXPERIMENTS
+    dbg = 0;        // timing experiments only (SR3_ATTN_DBG in the experiments build): 1 no scores, 2 no softmax, 4 no P v
+#endif
     const int Np = (N + 31) & ~31;
     const int ld = Np + 8;
     // XCD-aware block order (speed only): blocks b and b + 8 share an XCD, so every XCD gets a contiguous
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][mt][r] = 0.f;
-        if (wid * NTW < nkt) {
+        if (wid * NTW < nkt && !(dbg & 1)) {
             // the fragments of chunk ch + 1 are in flight while chunk ch multiplies (two register sets; rows of
             // tiles past the end are clamped duplicates whose scores are never stored)
             h16x8 ah[2][2], al[2][2], bh[2][NTW], bl[2][NTW];
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
     __syncthreads();
 
     // ---- softmax over keys (fp32, 8 lanes per query row), then P -> [8 hi halfs | 8 lo halfs] per 8 keys, in place ----
-    {
+    if (!(dbg & 2)) {
         const int row = tid >> 3, sub = tid & 7;
         float *sr = S + row * ld;
         float mx = -INFINITY;
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
                 }
         };
         fetch(std::integral_constant<int, 0>{}, 0);
-        for (int ks = 0; ks < nks; ks += 2) {
+        for (int ks = 0; ks < ((dbg & 4) ? 0 : nks); ks += 2) {
             fetch(std::integral_constant<int, 1>{}, min(ks + 1, nks - 1));
             mult(std::integral_constant<int, 0>{}, ks);
             if (ks + 1 < nks) {
@@ -918,6 +932,10 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
     hipLaunchKernelGGL(attention_vt_kernel, dim3(Np / 32, (C + 127) / 128, B), dim3(256), 0, s, qkv_split, N, C, vt);
     const size_t lds = (size_t)32 * (Np + 8) * sizeof(float);
     const int ntw = (Np / 16 + 3) / 4, ntc = (C / 16 + 3) / 4;
+    int dbg = 0;
+#ifdef SR3_EXPERIMENTS
+    if (const char *e = getenv("SR3_ATTN_DBG")) dbg = atoi(e);
+#endif
 #define SR3_AT(A, B_)                                                                                              \
     {                                                                                                              \
         static size_t attr = 0;                                                                                    \
@@ -927,7 +945,7 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
             attr = lds;                                                                                            \
         }                                                                                                          \
         hipLaunchKernelGGL((attention_split_kernel<A, B_>), dim3((Np / 32) * B), dim3(256), lds, s, qkv_split, vt, N, C, out, \
-                           out_split, ovf);                                                                        \
+                           out_split, ovf, dbg);                                                                   \
     }
     if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2)
     else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8)

@@ -143,6 +143,7 @@ struct sr3_ctx {
     float *part = nullptr;      // split-K partial sums (small-M convs)
     float *gscale = nullptr, *gshift = nullptr, *gpart = nullptr;
     float *temb = nullptr, *cbias = nullptr;
+    int cb_stride = 0;          // row stride of cbias: nf_total, or 0 when one noise level serves the whole batch (sampler steps)
 
     // schedule
     int T = 0;
@@ -641,7 +642,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.w = p.prec ? c->params[cv.w].dev_split : c->params[cv.w].dev;
     p.w_unscale = c->params[cv.w].w_unscale;
     p.bias = bias_override ? bias_override : (cv.b >= 0 ? c->params[cv.b].dev : nullptr);
-    p.chan_bias = chan_bias; p.chan_bias_stride = c->nf_total;
+    p.chan_bias = chan_bias; p.chan_bias_stride = c->cb_stride;
     p.resid = resid; p.out = out;
     if (c->prec) p.out_split = out_split;
     p.out_f32 = (out_f32 || !p.out_split.p) ? 1 : 0;
@@ -842,8 +843,12 @@ void run_embed(sr3_ctx *c, const float *nl, int stride, int B) {
     e.w2 = c->params[c->mlp_w2].dev; e.b2 = c->params[c->mlp_b2].dev;
     e.nfw = c->nfw; e.nfb = c->nfb; e.total = c->nf_total;
     e.temb = c->temb; e.chan_bias = c->cbias;
+    // sampler steps: the noise level is the same for every image (diffusion.py:166-167 repeats one scalar), so the
+    // embedding and the FeatureWiseAffine biases are computed ONCE and every conv reads row 0 (stride 0)
+    const bool uniform = stride == 0;
+    c->cb_stride = uniform ? 0 : c->nf_total;
     c->pbegin(F_EMBED);
-    launch_noise_embed(e, B, c->stream);
+    launch_noise_embed(e, uniform ? 1 : B, c->stream);
     c->pend();
 }
 
@@ -1416,6 +1421,16 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
     if (with_resid) p.resid = res;
     p.out = out;
+    // split-K exactly as the engine would choose it for this problem (partials on a scratch buffer)
+    float *part = nullptr;
+    {
+        const long Mo = (long)B * (up2 ? (Ho / 2) * (Wo / 2) : Ho * Wo);
+        p.splits = conv_splits(Mo, Cout, Cin);
+        if (p.splits > 1) {
+            HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * p.splits * Mo * Cout * sizeof(float)));
+            p.part = part;
+        }
+    }
     hipEvent_t e0, e1, e2;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1)); HIP_OK(hipEventCreate(&e2));
     auto go = [&]() { if (up2) launch_conv_up2(p, c->stream); else launch_conv(p, c->stream); };
@@ -1432,7 +1447,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     HIP_OK(hipEventElapsedTime(&ms, e1, e2));
     if (apply_ms) *apply_ms = ms / iters;
     HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1)); HIP_OK(hipEventDestroy(e2));
-    for (float *q : {i0.p, i1.p, act.p, out.p, res.p, w, bias, sc, sh, cb})
+    for (float *q : {i0.p, i1.p, act.p, out.p, res.p, w, bias, sc, sh, cb, part})
         if (q) HIP_OK(hipFree(q));
     HIP_OK(hipGetLastError());
     return 0;
