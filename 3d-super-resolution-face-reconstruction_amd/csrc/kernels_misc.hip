@@ -483,7 +483,11 @@ void launch_gn_apply_rows(const TDesc &in0, const TDesc &in1, int B, const float
 // pixels per block: enough blocks to keep every CU streaming (>= ~4 blocks of 512 threads per CU over
 // the whole grid), at least two items per thread
 static int ga_pixels_per_block(int B, int HW, int C8) {
-    int P = (1024 + B - 1) / B;                         // blocks per image wanted
+    int total = 1024;
+#ifdef SR3_EXPERIMENTS
+    if (const char *e = getenv("SR3_GN_BLOCKS")) total = atoi(e);
+#endif
+    int P = (total + B - 1) / B;                        // blocks per image wanted
     const int maxP = (HW * C8 + 2 * GA_T - 1) / (2 * GA_T);
     if (P > maxP) P = maxP;
     if (P < 1) P = 1;
