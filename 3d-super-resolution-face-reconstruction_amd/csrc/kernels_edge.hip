@@ -231,6 +231,13 @@ __global__ __launch_bounds__(256, 2) void conv_in_kernel(const _Float16 *__restr
                                                          const int nblocks) {
     constexpr int MT = 4;
     __shared__ double2 red[16][NT * 16];
+#ifndef SR3_CI_ROWSTORE
+#define SR3_CI_ROWSTORE 1
+#endif
+#if SR3_CI_ROWSTORE
+    constexpr int TLD = NT * 16 + 4;                     // floats per staged pixel row (+4: bank spread, 16-B aligned)
+    __shared__ __attribute__((aligned(16))) float tstage[4 * 16 * TLD];
+#endif
     const int H = out.H, W = out.W, Hp = H + 2, Wp = W + 2, HW = H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, q = lane >> 4;
@@ -305,6 +312,45 @@ __global__ __launch_bounds__(256, 2) void conv_in_kernel(const _Float16 *__restr
                 for (int j = 0; j < 4; ++j) out.p[rb[mt] + (unsigned)(j * Cout + nt * 16) + (unsigned)l16] = acc[mt][nt][j];
     }
     if (out_split.p != nullptr) {
+#if SR3_CI_ROWSTORE
+        // twin through an LDS transpose: the accumulator layout gives a lane 4 pixels x 1 channel (4-byte stores,
+        // 32-B runs); staged as [pixel][channel] a lane owns 8 consecutive channels of a pixel and stores its hi
+        // and lo halfs as two 16-B pieces of the 128-B chunk
+        float *T = tstage + wave * (16 * TLD);
+        constexpr int OCT = NT * 2;               // channel octets per pixel
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {         // one 16-pixel M-tile at a time (4.4 KB of LDS per wave)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[(4 * q + j) * TLD + nt * 16 + l16] = acc[mt][nt][j];
+            // a wave only reads what it wrote itself: no block barrier, just its own LDS writes completed
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+#pragma unroll
+            for (int k = 0; k < (16 * OCT + 63) / 64; ++k) {
+                const int item = lane + 64 * k;
+                if (item < 16 * OCT) {
+                    const int px = item / OCT, oct = item - px * OCT;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(T + px * TLD + oct * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(T + px * TLD + oct * 8 + 4);
+                    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    h16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = (_Float16)f[e];
+                        lo[e] = (_Float16)(f[e] - (float)hi[e]);
+                        const unsigned eb = (unsigned)__builtin_bit_cast(unsigned short, hi[e]) & 0x7C00u;
+                        range_bits = eb > range_bits ? eb : range_bits;
+                    }
+                    const size_t pixel = out.pix(n, ty[mt], tx[mt] + px);
+                    _Float16 *dst = reinterpret_cast<_Float16 *>(out_split.p + pixel * Cout + (oct >> 2) * 32) + (oct & 3) * 8;
+                    *reinterpret_cast<h16x8 *>(dst) = hi;
+                    *reinterpret_cast<h16x8 *>(dst + 32) = lo;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // the reads are done before the next M-tile overwrites T
+        }
+#else
         // per 32-channel chunk 32 hi halfs | 32 lo halfs; lanes l16, l16 ^ 1 hold neighbouring channels: the
         // even lane stores both hi halfs, the odd lane both lo halfs (split_pair_word)
         unsigned *tw = reinterpret_cast<unsigned *>(out_split.p);
@@ -321,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_in_kernel(const _Float16 *__restr
                     const unsigned ob = rb[mt] + (unsigned)(j * Cout + (nt >> 1) * 32);
                     tw[ob + (unsigned)((nt & 1) * 8) + lane_word] = word;
                 }
+#endif
     }
     if (stats != nullptr) {
 #pragma unroll
