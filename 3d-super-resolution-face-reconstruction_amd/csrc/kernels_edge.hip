@@ -177,7 +177,135 @@ __global__ __launch_bounds__(256, 3) void final_conv_kernel(const TDesc x, const
 
 } // namespace
 
+// -------------------------------------------------------------------------------------------------
+// final_conv, split-f16 mode: the conv is linear, so  out[p][o] = sum_tap y[p + tap][tap][o]  with
+// y[q][tap][o] = sum_c act[q][c] w[tap][c][o]  computed ONCE per input pixel — a [pixels] x [C] x [27 -> 32]
+// GEMM on v_mfma_f32_16x16x32_f16 whose A fragments come straight from the activation: lane (l16, q)
+// loads 8 consecutive channels of pixel l16 (32 B), applies the folded GroupNorm affine + Swish and
+// the hi / lo split in registers (every activation is evaluated once; the VALU form above evaluates
+// a 4 x 6 window per 2 x 4 outputs, 3x the tensor). Block = 8 x 32 output pixels: y of the 10 x 34
+// halo region (22 M-tiles of 16 pixels) goes to LDS, then every thread adds its pixel's 9 taps.
+// -------------------------------------------------------------------------------------------------
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void final_conv_mfma_kernel(const TDesc x, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              const h16x8 *__restrict__ wfr,   // [kstep][nt 2][hi|lo][lane 64]
+                                                              const float w_unscale, const float *__restrict__ bias,
+                                                              const TDesc out) {
+    constexpr int HR = 10, HC = 34, NPIX = HR * HC, MTILES = (NPIX + 15) / 16, YLD = 33;
+    __shared__ float Y[MTILES * 16 * YLD];
+    const int C = x.C, H = x.H, W = x.W, Cout = out.C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, q = lane >> 4;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8, n = blockIdx.z;
+    // weight fragments and this lane's GroupNorm scale / shift (channels 8q .. 8q + 7 of every 32-channel K-step)
+    h16x8 bh[KSTEPS][2], bl[KSTEPS][2];
+    float sc[KSTEPS][8], sh[KSTEPS][8];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bh[ks][nt] = wfr[((ks * 2 + nt) * 2 + 0) * 64 + lane];
+            bl[ks][nt] = wfr[((ks * 2 + nt) * 2 + 1) * 64 + lane];
+        }
+        const float *sp = scale + (size_t)n * C + ks * 32 + q * 8, *hp = shift + (size_t)n * C + ks * 32 + q * 8;
+        const f32x4 s0 = *reinterpret_cast<const f32x4 *>(sp), s1 = *reinterpret_cast<const f32x4 *>(sp + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(hp), h1 = *reinterpret_cast<const f32x4 *>(hp + 4);
+        sc[ks][0] = s0.x; sc[ks][1] = s0.y; sc[ks][2] = s0.z; sc[ks][3] = s0.w; sc[ks][4] = s1.x; sc[ks][5] = s1.y; sc[ks][6] = s1.z; sc[ks][7] = s1.w;
+        sh[ks][0] = h0.x; sh[ks][1] = h0.y; sh[ks][2] = h0.z; sh[ks][3] = h0.w; sh[ks][4] = h1.x; sh[ks][5] = h1.y; sh[ks][6] = h1.z; sh[ks][7] = h1.w;
+    }
+    for (int mt = wave; mt < MTILES; mt += 4) {
+        const int p = min(mt * 16 + l16, NPIX - 1);              // halo-region pixel of this lane's A row
+        const int hy = p / HC, hx = p - hy * HC;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;   // zero padding AFTER the activation
+        const float *src = x.p + x.pix(n, min(max(yy, -1), H), min(max(xx, -1), W)) * (size_t)C + q * 8;
+        f32x4 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + ks * 32), v1 = *reinterpret_cast<const f32x4 *>(src + ks * 32 + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            h16x8 ah, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = swish_fast(fmaf(f[e], sc[ks][e], sh[ks][e]));
+                a = ok ? a : 0.f;
+                ah[e] = (_Float16)a;
+                al[e] = (_Float16)(a - (float)ah[e]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks][nt], acc[nt], 0, 0, 0);
+            }
+        }
+        // C/D map: col = l16 (+ 16 nt) = tap * 3 + o, row = 4 q + j = pixel of the M-tile
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Y[(mt * 16 + 4 * q + j) * YLD + nt * 16 + l16] = acc[nt][j] * w_unscale;
+    }
+    __syncthreads();
+    const int oy = threadIdx.x >> 5, ox = threadIdx.x & 31;
+    const int yy = y0 + oy, xx = x0 + ox;
+    if (yy < H && xx < W) {
+        float o3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float *yp = Y + ((oy + dy) * HC + ox + dx) * YLD + (dy * 3 + dx) * 3;
+                for (int o = 0; o < Cout; ++o) o3[o] += yp[o];
+            }
+        float *op = out.p + out.pix(n, yy, xx) * (size_t)Cout;
+        for (int o = 0; o < Cout; ++o) op[o] = o3[o] + bias[o];
+    }
+}
+
 bool final_conv_supported(int C, int Cout) { return (C % 64) == 0 && Cout >= 1 && Cout <= 4; }
+// MFMA form (split-f16 mode): 27 (tap, output) columns in two 16-wide tiles
+bool final_conv_mfma_supported(int C, int Cout) { return Cout == 3 && (C == 32 || C == 64 || C == 128); }
+size_t final_conv_mfma_weight_floats(int C) { return (size_t)(C / 32) * 2 * 2 * 64 * 4; }
+
+// OIHW [3][C][3][3] -> B fragments [kstep][nt][hi|lo][lane][8 halfs]: lane (l16, q) holds column nt*16 + l16 =
+// tap*3 + o (columns >= 27 zero), k = channels kstep*32 + 8q .. + 7; scaled by 2^k (max|w| 2^k in [1024, 2048))
+float pack_final_conv_mfma_weight(const float *oihw, int C, float *dst_as_float) {
+    const int k = split_scale_exponent(oihw, (size_t)3 * C * 9);
+    const float scl = ldexpf(1.0f, k);
+    _Float16 *d = reinterpret_cast<_Float16 *>(dst_as_float);
+    for (int ks = 0; ks < C / 32; ++ks)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int l16 = lane & 15, q = lane >> 4, col = nt * 16 + l16;
+                for (int e = 0; e < 8; ++e) {
+                    float v = 0.f;
+                    if (col < 27) {
+                        const int tap = col / 3, o = col - tap * 3, c = ks * 32 + q * 8 + e;
+                        v = oihw[((size_t)o * C + c) * 9 + tap] * scl;
+                    }
+                    const _Float16 hi = (_Float16)v;
+                    d[((((size_t)ks * 2 + nt) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    d[((((size_t)ks * 2 + nt) * 2 + 1) * 64 + lane) * 8 + e] = (_Float16)(v - (float)hi);
+                }
+            }
+    return ldexpf(1.0f, -k);
+}
+
+void launch_final_conv_mfma(const TDesc &x, int B, const float *scale, const float *shift, const float *wfr, float w_unscale,
+                            const float *bias, const TDesc &out, hipStream_t s) {
+    const dim3 grid((x.W + 31) / 32, (x.H + 7) / 8, B);
+    const h16x8 *w = reinterpret_cast<const h16x8 *>(wfr);
+    switch (x.C / 32) {
+    case 1: hipLaunchKernelGGL(final_conv_mfma_kernel<1>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out); break;
+    case 2: hipLaunchKernelGGL(final_conv_mfma_kernel<2>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out); break;
+    default: hipLaunchKernelGGL(final_conv_mfma_kernel<4>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out); break;
+    }
+}
 
 // OIHW [Cout][C][3][3] -> [tap][C][4] (output channel padded to 4 floats)
 void pack_final_conv_weight(const float *oihw, int Cout, int C, float *dst) {

@@ -114,6 +114,8 @@ struct sr3_ctx {
     ConvRef final_conv;
     int mlp_w1 = -1, mlp_b1 = -1, mlp_w2 = -1, mlp_b2 = -1;
     float *final_wq = nullptr;             // final_conv weights as [9][C][4] for the fused VALU kernel (kernels_edge.hip)
+    float *final_wm = nullptr;             // final_conv weights as MFMA fragments (split-f16 mode, final_conv_mfma_kernel)
+    float final_unscale = 1.0f;
     float *ci_w = nullptr;                 // downs.0 weights as MFMA fragments for conv_in_kernel (split-f16 mode)
     float ci_unscale = 1.0f;
     float *nfw = nullptr, *nfb = nullptr;  // concatenated FeatureWiseAffine linears
@@ -359,6 +361,10 @@ int alloc_weights(sr3_ctx *c) {
     if (final_conv_supported(c->final_conv.cin, c->final_conv.cout)) {
         HIP_OK(hipMalloc(&c->final_wq, (size_t)9 * c->final_conv.cin * 4 * sizeof(float)));
         c->weight_bytes += (uint64_t)9 * c->final_conv.cin * 4 * sizeof(float);
+    }
+    if (final_conv_mfma_supported(c->final_conv.cin, c->final_conv.cout)) {
+        HIP_OK(hipMalloc(&c->final_wm, final_conv_mfma_weight_floats(c->final_conv.cin) * sizeof(float)));
+        c->weight_bytes += final_conv_mfma_weight_floats(c->final_conv.cin) * sizeof(float);
     }
     if (c->cfg.in_channel <= 8 && (c->cfg.inner_channel % 32) == 0 && c->cfg.inner_channel <= 64) {
         HIP_OK(hipMalloc(&c->ci_w, conv_in_weight_floats(c->cfg.inner_channel) * sizeof(float)));
@@ -824,10 +830,17 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
                                     c->gpart, c->gscale, c->gshift, c->stream);
         c->pend();
         c->pbegin(F_CONV);
-        launch_final_conv(cur, B, c->gscale, c->gshift, c->final_wq, c->params[c->final_conv.b].dev, c->eps, c->stream);
+        static const bool final_valu = getenv("SR3_FINAL_VALU") && atoi(getenv("SR3_FINAL_VALU"));   // A/B: fp32 VALU form in f16x3 mode
+        const bool mfma = c->prec && c->final_wm && !final_valu;
+        if (mfma)
+            launch_final_conv_mfma(cur, B, c->gscale, c->gshift, c->final_wm, c->final_unscale, c->params[c->final_conv.b].dev,
+                                   c->eps, c->stream);
+        else
+            launch_final_conv(cur, B, c->gscale, c->gshift, c->final_wq, c->params[c->final_conv.b].dev, c->eps, c->stream);
         if (c->prof) {
             char tag[160];
-            snprintf(tag, sizeof tag, "final_conv gn+swish+k3 %dx%d cin%d cout%d fp32-valu", H, W, cur.C, c->final_conv.cout);
+            snprintf(tag, sizeof tag, "final_conv gn+swish+k3 %dx%d cin%d cout%d %s", H, W, cur.C, c->final_conv.cout,
+                     mfma ? "per-pixel-mfma16+gather" : "fp32-valu");
             c->pend(2.0 * (double)B * H * W * c->final_conv.cout * 9.0 * cur.C, tag);
         }
         return;
@@ -1054,6 +1067,7 @@ void sr3_destroy(sr3_ctx *c) {
     }
     if (c->final_wq) (void)hipFree(c->final_wq);
     if (c->ci_w) (void)hipFree(c->ci_w);
+    if (c->final_wm) (void)hipFree(c->final_wm);
     if (c->nfw) (void)hipFree(c->nfw);
     if (c->nfb) (void)hipFree(c->nfb);
     if (c->arena) (void)hipFree(c->arena);
@@ -1121,6 +1135,11 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
                 std::vector<float> wf(conv_in_weight_floats(p.cout));
                 c->ci_unscale = pack_conv_in_weight(host, p.cout, p.cin, wf.data());
                 HIP_OK(hipMemcpy(c->ci_w, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            if (c->final_wm && &p == &c->params[c->final_conv.w]) {
+                std::vector<float> wf(final_conv_mfma_weight_floats(p.cin));
+                c->final_unscale = pack_final_conv_mfma_weight(host, p.cin, wf.data());
+                HIP_OK(hipMemcpy(c->final_wm, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             if (c->final_wq && &p == &c->params[c->final_conv.w]) {
                 std::vector<float> wq((size_t)9 * p.cin * 4);

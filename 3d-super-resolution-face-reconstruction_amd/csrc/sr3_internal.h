@@ -223,6 +223,12 @@ void pack_final_conv_weight(const float *oihw, int Cout, int C, float *dst);
 void launch_final_conv(const TDesc &x, int B, const float *scale, const float *shift, const float *wq, const float *bias,
                        const TDesc &out, hipStream_t s);
 
+// the same conv in split-f16 mode as a per-pixel [C] x [27 -> 32] MFMA GEMM + a 9-tap gather (kernels_edge.hip)
+bool final_conv_mfma_supported(int C, int Cout);
+size_t final_conv_mfma_weight_floats(int C);
+float pack_final_conv_mfma_weight(const float *oihw, int C, float *dst_as_float);
+void launch_final_conv_mfma(const TDesc &x, int B, const float *scale, const float *shift, const float *wfr, float w_unscale,
+                            const float *bias, const TDesc &out, hipStream_t s);
 // downs.0 (Conv3x3 in_channel <= 8 -> Cout) on the packed split-f16 state: xp = [B][H+2][W+2] pixels of
 // 16 halfs (8 channels hi | lo; + 16 floats of slack behind the last pixel), wci from pack_conv_in_weight
 bool conv_in_supported(int Cin, int Cout, int H, int W);
