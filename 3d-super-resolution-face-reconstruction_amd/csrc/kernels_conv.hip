@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
 
 namespace sr3 {
 
@@ -214,7 +215,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 // colbias[BN] (LDS, staged by the producers at kernel start so that no global load sits on the
 // epilogue's critical path): bias + FeatureWiseAffine bias when the whole tile lies in one image
 // (flag in colbias[BN]); otherwise bias only and the per-image part is gathered per row.
-template <int BM, int BN, int WGM, int WGN, int MT, int NT>
+// QRED (persistent kernel): the four row groups of a wave are added by lane exchange first, only lanes q == 0
+// write [wm][column] entries (a quarter of the staging space) and the caller does the barrier
+template <int BM, int BN, int WGM, int WGN, int MT, int NT, bool QRED = false>
 __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc)[MT][NT], float *smem,
                                                 const int *rowpix, const int *rowimg, int m0, int n0, int M, int wm,
                                                 int wn, int l16, int q, const float *colbias) {
@@ -329,10 +332,16 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
                     const double v = (double)acc[mt][nt][j];
                     st1 += v; st2 = fma(v, v, st2);
                 }
-            reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+            if (QRED) {
+                st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+                st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+                if (q == 0) reinterpret_cast<double2 *>(smem)[wm * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+            } else {
+                reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!QRED) __syncthreads();
     }
 }
 
@@ -876,8 +885,12 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         __builtin_amdgcn_s_setprio(1);      // consumers win issue arbitration against the DMA waves
 #endif
         const float *aptr_h[MT], *aptr_l[MT];   // variant >= 1: fragment addresses of the NEXT K-step, computed early
+        // ONESEG: the WM rows of a wave lie in one row segment (SEG is a power of two >= SEGMIN), so row tile mt
+        // is tile 0 + 16 * mt ring rows with the same swizzle term: one address pair per K-step, the other row
+        // tiles are constant offsets of the reads (half the address arithmetic, two registers less)
+        constexpr bool ONESEG = (SEGMIN % WM) == 0;
 #define SR3_AADDR(MTI, KT)                                                                         \
-    {                                                                                              \
+    if (!ONESEG || (MTI) == 0) {                                                                   \
         const int kt_ = (KT);                                                                      \
         const bool halo_ = kt_ < nkh;                                                              \
         const int g_ = kt_ / KS;                                                                   \
@@ -890,8 +903,9 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     }
 #define SR3_AREAD2(MTI)                                                                            \
     {                                                                                              \
-        ah[MTI] = *reinterpret_cast<const h16x8 *>(aptr_h[MTI]);                                   \
-        al[MTI] = *reinterpret_cast<const h16x8 *>(aptr_l[MTI]);                                   \
+        const int ai_ = ONESEG ? 0 : (MTI), ao_ = ONESEG ? (MTI) * 16 * ROWF : 0;                  \
+        ah[MTI] = *reinterpret_cast<const h16x8 *>(aptr_h[ai_] + ao_);                             \
+        al[MTI] = *reinterpret_cast<const h16x8 *>(aptr_l[ai_] + ao_);                             \
     }
 #define SR3_AREAD(MTI, KT)                                                                         \
     {                                                                                              \
@@ -1064,6 +1078,395 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, 0, 1);
 }
 
+#ifdef SR3_EXPERIMENTS
+// =================================================================================================
+// EXPERIMENT (libsr3hip_exp.so only, SR3_PERSIST=1; results are correct — the conv / UNet / sampler GPU tests
+// pass with it — but it is 1.4x SLOWER than the one-tile kernel: 0.35 vs 0.25 ms on the 128x128-pixel
+// 64-channel conv, +1.0 ms per B=64 step; profiles/README.md finding 38). Kept as the measured record of
+// the "hide the tile prologue behind the previous epilogue" idea.
+// Persistent form of the x-halo kernel (16x16x32 consumers, four waves stacked along M): a block walks
+// over tiles v = blockIdx.x, + gridDim.x, ... . What it buys: while the consumer waves run the epilogue
+// of tile i, the producer waves set up tile i + 1 (tables, addresses) and put its first A halo group
+// and first B tile in flight — the LDS rings are free once the last K-step of tile i has been read —
+// so a tile's launch / set-up / first-DMA latency (10 % of a 128x128-pixel, 64-channel conv) hides
+// behind the previous epilogue. What makes it fit the same registers and LDS as the one-tile kernel:
+// the consumer state is tile independent (fragment row offsets depend on the lane only), the per-tile
+// tables are double-buffered (1.3 KB), and the statistics hand-off is reduced over the four row groups
+// of a wave by lane exchange, so it fits B stage 1 (free between two tiles) instead of a region of its own.
+// Barriers per tile, identical on both sides: nk K-step barriers + F (end of K loop) + E (statistics
+// staged; only with fused statistics). The consumers' first barrier of a tile is the producers' K-step-0
+// barrier of that tile.
+// =================================================================================================
+template <int BM, int BN, int SEGMIN, int KS>
+__global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const ConvParams p_in, const int ntiles,
+                                                                             const int stagger) {
+    const ConvParams p = phase_params(p_in, blockIdx.z);
+    // Resident blocks of a CU that start together and walk over equal tiles stay in lockstep: all in their K
+    // loops, then all in their epilogues (MI355X_MICROARCH.md, "try a stagger"). The k-th wave of blocks
+    // (blockIdx.x / stagger_group) starts k * stagger shader cycles late so the phases interleave.
+    if (stagger > 0) {
+        const int late = (blockIdx.x / (gridDim.x / 3 > 0 ? gridDim.x / 3 : 1)) * stagger;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < late) __builtin_amdgcn_s_sleep(16);
+    }
+    constexpr int WGM = 4, WGN = 1;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int HALO = KS - 1, TAPS = KS * KS;
+    constexpr int RA = (BM + HALO * (BM / SEGMIN) + 7) / 8 * 8;
+    constexpr int ARH = (RA / 8 + 3) / 4;
+    constexpr int ASTG = RA * ROWF, BSTG = BN * ROWF;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int TBL = 2 * BM + BN + 4;            // ints / floats of the epilogue tables: rowpix | rowimg | colbias + flag
+    static_assert((NT % 2) == 0 && (RA % 8) == 0, "tile shape");
+    static_assert((size_t)WGM * BN * sizeof(double2) <= (size_t)BSTG * sizeof(float), "statistics staging fits one B stage");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Aring = smem;                    // [2][RA][32]
+    float *Bring = smem + 2 * ASTG;         // [2][BN][32]
+    float *tables = smem + 2 * ASTG + 2 * BSTG;     // [TBL], ONE set (a second one would cost the third block per CU: LDS is
+                                                    // allocated in 1280-B granules): written by the producers right behind a
+                                                    // tile's K-step-0 barrier, when every consumer has left the previous epilogue
+    float *stat_stage = Bring + BSTG;       // B stage 1: free from the end of a tile's K loop to K-step 1 of the next
+
+    const int C0 = p.in0.C, C1 = p.in1.p ? p.in1.C : 0;
+    const int Cin = C0 + C1;
+    const int Cout = p.out.C;
+    const int W = p.Wout;
+    const int HWo = p.Hout * W;
+    const int M = p.B * HWo;
+    const int tilesN = Cout / BN;
+    const int SEG = min(W, BM), SEGP = SEG + HALO, nseg = BM / SEG;
+    const int rows_a = nseg * SEGP;
+    const int nkh = TAPS * (Cin / BK);
+    const int C2a = p.in2.p ? p.in2.C : 0, C2 = C2a + (p.in2b.p ? p.in2b.C : 0);
+    const int nk = nkh + C2 / BK;
+    const int G = nkh / KS;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool has_stats = p.stats != nullptr;
+    // XCD-aware order of the virtual tile ids (speed only): ids v and v + 8 run on one XCD
+    auto tile_of = [&](int v, int &m0, int &n0) {
+        const int xcd = v & 7, loc = v >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
+        m0 = (bid / tilesN) * BM;
+        n0 = (bid % tilesN) * BN;
+    };
+
+    if (wid >= 4) {
+        // ------------------------------- producer waves -------------------------------------
+        const int w = wid - 4;
+        const int tid = threadIdx.x - 256;
+        const int rsub = lane >> 3;
+        const unsigned schunk16 = (unsigned)(((lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7)) * 16);
+        const int Hp = p.in0.Hp(), Wp = p.in0.Wp();
+        const size_t tapstride = (size_t)Cout * Cin;
+        unsigned vH0[ARH], vH1[ARH], vB[BR], vB2[BR], vA2[AR], vA2b[AR];
+        int m0 = 0, n0 = 0;
+        // epilogue tables of tile (tm0, tn0)
+        auto setup_tables = [&](int tm0, int tn0) {
+            int *rowpix = reinterpret_cast<int *>(tables);
+            int *rowimg = rowpix + BM;
+            float *colbias = reinterpret_cast<float *>(rowimg + BM);
+            const int m0 = tm0, n0 = tn0;
+            if (tid < BM) {
+                const int m = min(m0 + tid, M - 1);
+                const int n = div_hw(p, m, HWo);
+                const int rem = m - n * HWo;
+                const int oy = div_w(p, rem, W);
+                rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
+                rowimg[tid] = n;
+            }
+            {
+                const int img_a = div_hw(p, m0, HWo), img_b = div_hw(p, min(m0 + BM - 1, M - 1), HWo);
+                const bool one = img_a == img_b;
+                if (tid < BN) {
+                    const int nc = min(n0 + tid, Cout - 1);
+                    float v = p.bias ? p.bias[nc] : 0.f;
+                    if (p.chan_bias != nullptr && one) v += p.chan_bias[(size_t)img_a * p.chan_bias_stride + nc];
+                    colbias[tid] = v;
+                }
+                if (tid == 0) reinterpret_cast<int *>(colbias)[BN] = one ? 1 : 0;
+            }
+        };
+        // DMA addresses of tile (m0, n0)
+        auto setup = [&]() {
+            static_for<ARH>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int R = (4 * i + w) * 8 + rsub;
+                int sg = R / SEGP, jx = R - sg * SEGP;
+                if (sg >= nseg) { sg = nseg - 1; jx = 0; }
+                const int m = m0 + sg * SEG;
+                const int n = div_hw(p, m, HWo);
+                const int rem = m - n * HWo;
+                const int y = div_w(p, rem, W), x0 = rem - y * W;
+                const unsigned pix = (unsigned)((n * Hp + y + p.org_y) * Wp + x0 + jx + p.org_x);
+                vH0[i] = pix * (unsigned)C0 * 4u + schunk16;
+                vH1[i] = pix * (unsigned)C1 * 4u + schunk16;
+            });
+            static_for<BR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int n = min(n0 + (4 * i + w) * 8 + rsub, Cout - 1);
+                vB[i] = (unsigned)n * (unsigned)Cin * 4u + schunk16;
+                vB2[i] = (unsigned)n * (unsigned)C2 * 4u + schunk16;
+            });
+            static_for<AR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int m = min(m0 + (4 * i + w) * 8 + rsub, M - 1);
+                const int n = div_hw(p, m, HWo);
+                const int rem = m - n * HWo;
+                const int oy = div_w(p, rem, W);
+                vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * W) * (unsigned)C2a * 4u + schunk16 : 0u;
+                vA2b[i] = C2 > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * W) * (unsigned)(C2 - C2a) * 4u + schunk16 : 0u;
+            });
+        };
+        int ga = 0;
+#define SR3_ISSUE_HALO(C0A, DY)                                                                    \
+    {                                                                                              \
+        const int c0a_ = (C0A);                                                                    \
+        const bool first_ = c0a_ < C0;                                                             \
+        const int Cs_ = first_ ? C0 : C1;                                                          \
+        const char *ab_ = reinterpret_cast<const char *>((first_ ? p.in0.p : p.in1.p) + (first_ ? c0a_ : c0a_ - C0)) + \
+                          (size_t)(DY) * Wp * Cs_ * 4;                                             \
+        float *Ad_ = Aring + (ga & 1) * ASTG + w * 256;                                            \
+        static_for<ARH>([&](auto ic) {                                                             \
+            constexpr int i = decltype(ic)::value;                                                 \
+            if ((4 * i + w) * 8 < rows_a)                                                          \
+                dma16(reinterpret_cast<const float *>(ab_ + (first_ ? vH0[i] : vH1[i])), Ad_ + i * 1024); \
+        });                                                                                        \
+        ++ga;                                                                                      \
+    }
+        // first operands of a tile: halo group (chunk 0, dy 0) into A stage 0, B tile of K-step 0 into B stage 0
+        auto issue_first = [&]() {
+            ga = 0;
+            SR3_ISSUE_HALO(0, 0)
+            const char *wb = reinterpret_cast<const char *>(p.w);
+            float *Bd = Bring + w * 256;
+            static_for<BR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+            });
+        };
+        int v = blockIdx.x;
+        if (v < ntiles) {
+            tile_of(v, m0, n0);
+            setup();
+            issue_first();
+        }
+        for (; v < ntiles; v += gridDim.x) {
+            const int m0_cur = m0, n0_cur = n0;
+            int k = 0;
+            for (int c0 = 0; c0 < Cin; c0 += BK) {
+                const char *wbase = reinterpret_cast<const char *>(p.w + c0);
+                static_for<TAPS>([&](auto tc) {
+                    constexpr int tap = decltype(tc)::value;
+                    constexpr int dy = tap / KS, dx = tap % KS;
+                    if (dx == 1) {          // the stage of group g-1 is free once K-step KS*g - 1 has been read
+                        if (dy < KS - 1) {
+                            SR3_ISSUE_HALO(c0, dy + 1)
+                        } else if (c0 + BK < Cin) {
+                            SR3_ISSUE_HALO(c0 + BK, 0)
+                        }
+                    }
+                    if (k > 0) {            // (K-step 0's B tile went out with the tile's first operands)
+                        float *Bd = Bring + (k & 1) * BSTG + w * 256;
+                        const char *wb = wbase + (size_t)tap * tapstride * 4;
+                        static_for<BR>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                        });
+                    }
+                    producer_sync<0>();
+                    if (k == 0) setup_tables(m0_cur, n0_cur);
+                    ++k;
+                });
+            }
+            // fused 1x1 term: plain BM-row A tiles continue in the A ring
+            for (int c0 = 0; c0 < C2; c0 += BK) {
+                float *Ad = Aring + (ga & 1) * ASTG + w * 256;
+                float *Bd = Bring + (k & 1) * BSTG + w * 256;
+                const bool first2 = c0 < C2a;
+                const char *ab = reinterpret_cast<const char *>(first2 ? p.in2.p + c0 : p.in2b.p + (c0 - C2a));
+                const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
+                static_for<AR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16(reinterpret_cast<const float *>(ab + (first2 ? vA2[i] : vA2b[i])), Ad + i * 1024);
+                });
+                static_for<BR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
+                });
+                producer_sync<0>();
+                ++k;
+                ++ga;
+            }
+            producer_sync<0>();             // F: the consumers have read the last K-step
+            // next tile: tables, addresses and first operands while the consumers run this tile's epilogue
+            const int vn = v + gridDim.x;
+            if (vn < ntiles) {
+                tile_of(vn, m0, n0);
+                setup();
+                issue_first();
+            }
+            if (has_stats) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();               // E: this tile's column sums are staged (not a DMA wait)
+                const double2 *red = reinterpret_cast<const double2 *>(stat_stage);
+                if (tid < BN) {
+                    double a = 0, b = 0;
+#pragma unroll
+                    for (int j = 0; j < WGM; ++j) { const double2 t2 = red[j * BN + tid]; a += t2.x; b += t2.y; }
+                    const int n = m0_cur / HWo, slice = p.stats_slice0 + (m0_cur - n * HWo) / BM;
+                    double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0_cur + tid) * 2;
+                    o[0] = a; o[1] = b;
+                }
+            }
+        }
+#undef SR3_ISSUE_HALO
+        return;
+    }
+
+    // ----------------------------------- consumer waves -----------------------------------------
+    const int l16 = lane & 15, q = lane >> 4;
+    const int wm = wid, wn = 0;
+    const int swzB = (l16 >> 1) & 7;
+    const float *Bbase = Bring + (wn * WN + l16) * ROWF;
+    const int bho = ((q ^ swzB) & 7) * 4, blo = (((4 + q) ^ swzB) & 7) * 4;
+    static_assert(SEGMIN % WM == 0, "a wave's rows lie in one row segment");
+    const int rplain0 = wm * WM + l16;
+    const int rhalo0 = rplain0 + HALO * (rplain0 / SEG);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int m0, n0;
+        tile_of(v, m0, n0);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
+        h16x8 ah[MT], al[MT], bqh[2], bql[2];
+        const float *aptr_h, *aptr_l;
+        // (SEGMIN >= WM: the WM rows of a wave lie in one row segment, so row tile mt is tile 0 + 16 * mt ring
+        // rows with the same swizzle term — one address pair per K-step, the other tiles are constant offsets)
+#define SR3_AADDR(MTI, KT)                                                                         \
+    if ((MTI) == 0) {                                                                              \
+        const int kt_ = (KT);                                                                      \
+        const bool halo_ = kt_ < nkh;                                                              \
+        const int g_ = kt_ / KS;                                                                   \
+        const int astage_ = halo_ ? (g_ & 1) : ((G + kt_ - nkh) & 1);                              \
+        const int R_ = halo_ ? rhalo0 + (kt_ - KS * g_) : rplain0;                                 \
+        const int sw_ = (R_ >> 1) & 7;                                                             \
+        const float *Ar_ = Aring + astage_ * ASTG + R_ * ROWF;                                     \
+        aptr_h = Ar_ + ((q ^ sw_) & 7) * 4;                                                        \
+        aptr_l = Ar_ + (((4 + q) ^ sw_) & 7) * 4;                                                  \
+    }
+#define SR3_AREAD2(MTI)                                                                            \
+    {                                                                                              \
+        ah[MTI] = *reinterpret_cast<const h16x8 *>(aptr_h + (MTI) * 16 * ROWF);                    \
+        al[MTI] = *reinterpret_cast<const h16x8 *>(aptr_l + (MTI) * 16 * ROWF);                    \
+    }
+#define SR3_BREAD(BUF, NTI, KT)                                                                    \
+    {                                                                                              \
+        const float *Bb_ = Bbase + ((KT) & 1) * BSTG + (NTI) * 16 * ROWF;                          \
+        bqh[BUF] = *reinterpret_cast<const h16x8 *>(Bb_ + bho);                                    \
+        bql[BUF] = *reinterpret_cast<const h16x8 *>(Bb_ + blo);                                    \
+    }
+#define SR3_MMA16(MTI, NTI, BUF)                                                                   \
+    {                                                                                              \
+        acc[MTI][NTI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[MTI], bqh[BUF], acc[MTI][NTI], 0, 0, 0); \
+        acc[MTI][NTI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[MTI], bql[BUF], acc[MTI][NTI], 0, 0, 0); \
+        acc[MTI][NTI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[MTI], bqh[BUF], acc[MTI][NTI], 0, 0, 0); \
+    }
+        __syncthreads();                            // K-step 0 of this tile has landed
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { SR3_AADDR(mt, 0) SR3_AREAD2(mt) }
+        SR3_BREAD(0, 0, 0)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int kn = min(kt + 1, nk - 1);     // after the last K-step: re-read, unused
+#pragma unroll
+            for (int nt = 0; nt < NT - 1; ++nt) {
+                SR3_BREAD((nt + 1) & 1, nt + 1, kt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) SR3_MMA16(mt, nt, nt & 1)
+                if (nt == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) SR3_AADDR(mt, kn)
+                }
+            }
+            __syncthreads();
+            SR3_BREAD(0, 0, kn)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                SR3_MMA16(mt, NT - 1, (NT - 1) & 1)
+                __builtin_amdgcn_sched_barrier(0);
+                SR3_AREAD2(mt)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef SR3_AADDR
+#undef SR3_AREAD2
+#undef SR3_BREAD
+#undef SR3_MMA16
+        // The epilogue re-reads its parameters from the kernel-argument segment through a pointer the optimiser
+        // cannot see through: otherwise ~15 pointers / scalars are hoisted out of the tile loop, stay live across
+        // the K loop, and the 80-register budget of this tile shape spills inside the K loop. (KS == 3: no
+        // sub-pixel phases, so the phase-adjusted copy equals the argument itself.)
+        typedef const unsigned __attribute__((address_space(4))) *KArgW;
+        typedef unsigned __attribute__((may_alias)) AliasWord;      // (the copy is read back as floats and pointers)
+        KArgW pq = (KArgW)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pq));
+        ConvParams pl;
+        static_assert(sizeof(ConvParams) % 4 == 0, "word copy");
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(ConvParams) / 4); ++i) reinterpret_cast<AliasWord *>(&pl)[i] = pq[i];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] *= pl.w_unscale;
+        const int *rowpix = reinterpret_cast<const int *>(tables);
+        const int *rowimg = rowpix + BM;
+        const float *colbias = reinterpret_cast<const float *>(rowimg + BM);
+        // (same for the lane-derived offsets of the epilogue: made opaque per tile so they are recomputed here
+        // instead of being carried through the K loop)
+        int l16e = l16, qe = q;
+        asm volatile("" : "+v"(l16e), "+v"(qe));
+        conv_epilogue16<BM, BN, WGM, WGN, MT, NT, true>(pl, acc, stat_stage, rowpix, rowimg, m0, n0, M, wm, wn, l16e, qe, colbias);
+        if (has_stats) __syncthreads();             // E: column sums staged for the producer threads
+    }
+}
+
+template <int BM, int BN, int SEGMIN, int KS>
+void launch_halo_pt(const ConvParams &p, hipStream_t s) {
+    static bool attr_set = false;
+    static int cus = 0;
+    constexpr int RA = (BM + (KS - 1) * (BM / SEGMIN) + 7) / 8 * 8;
+    constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM + BN + 4) * sizeof(float);
+    auto kern = conv3x3_halo_pt<BM, BN, SEGMIN, KS>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        attr_set = true;
+    }
+    const int M = p.B * p.Hout * p.Wout;
+    const int ntiles = (M / BM) * (p.out.C / BN);
+    // resident blocks per CU: LDS comes in 1280-byte granules (160 KiB = 128 of them)
+    const int granules = ((int)lds + 1279) / 1280;
+    const int per_cu = std::min(128 / granules, BN == 64 ? 3 : 2);
+    int grid = cus * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    static const int stagger = getenv("SR3_PT_STAGGER") ? atoi(getenv("SR3_PT_STAGGER")) : 0;
+    hipLaunchKernelGGL(kern, dim3(grid, 1, p.phases), dim3(512), lds, s, p, ntiles, stagger);
+}
+
+#endif  // SR3_EXPERIMENTS
+
 template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
 void launch_halo(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
@@ -1086,6 +1489,14 @@ static bool halo_mfma16() {
     static const int v = getenv("SR3_MFMA16") ? atoi(getenv("SR3_MFMA16")) : 1;
     return v != 0;
 }
+
+#ifdef SR3_EXPERIMENTS
+// persistent-tile form of the halo kernel (conv3x3_halo_pt, experiment): SR3_PERSIST=1
+static bool halo_persistent() {
+    static const int v = getenv("SR3_PERSIST") ? atoi(getenv("SR3_PERSIST")) : 0;
+    return v != 0;
+}
+#endif
 
 // preconditions of the x-halo kernel for tile height BM
 static bool halo_ok(const ConvParams &p, int BM, int segmin, int bn) {
@@ -1282,6 +1693,10 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
         if (halo_ok(p, 128, 32, 64)) {
+#ifdef SR3_EXPERIMENTS
+            if (halo_mfma16() && halo_persistent() && p.ks == 3) launch_halo_pt<128, 64, 32, 3>(p, s);
+            else
+#endif
             if (halo_mfma16()) { if (p.ks == 3) launch_halo<128, 64, 4, 1, 32, 3, 16>(p, s); else launch_halo<128, 64, 4, 1, 32, 2, 16>(p, s); }
             else { if (p.ks == 3) launch_halo<128, 64, 2, 2, 32, 3, 32>(p, s); else launch_halo<128, 64, 2, 2, 32, 2, 32>(p, s); }
         }
@@ -1289,7 +1704,10 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         break;
     case 2: launch_cfg<64, 64, 2, 2>(p, s); break;
     default:
-        if (halo_ok(p, 128, 8, 128)) {
+        if (halo_mfma16() && halo_ok(p, 128, 32, 128)) {   // rows of 32+ pixels: one row segment per wave (ONESEG)
+            if (p.ks == 3) launch_halo<128, 128, 4, 1, 32, 3, 16>(p, s); else launch_halo<128, 128, 4, 1, 32, 2, 16>(p, s);
+        }
+        else if (halo_ok(p, 128, 8, 128)) {
             if (halo_mfma16()) { if (p.ks == 3) launch_halo<128, 128, 4, 1, 8, 3, 16>(p, s); else launch_halo<128, 128, 4, 1, 8, 2, 16>(p, s); }
             else { if (p.ks == 3) launch_halo<128, 128, 2, 2, 8, 3, 32>(p, s); else launch_halo<128, 128, 2, 2, 8, 2, 32>(p, s); }
         }
