@@ -521,7 +521,8 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             if (r < nk) producer_sync<r * (AR + BR)>();
         });
         __syncthreads();
-        if (p.stats != nullptr) producer_stats_tail<BM, BN, WGM>(p, smem, m0, n0, HWo);
+        // (in-place split-K: the consumer waves of the tile's last block write the statistics themselves)
+        if (p.stats != nullptr && nsplit == 1) producer_stats_tail<BM, BN, WGM>(p, smem, m0, n0, HWo);
         return;
     }
 
@@ -634,6 +635,91 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= p.w_unscale;
     }
 
+    if constexpr (BM == 64 && BN == 64) {
+    if (nsplit > 1 && p.tile_cnt != nullptr) {
+        // In-place split-K (64x64 tiles; launch_conv guarantees whole tiles in M and N): every block leaves its
+        // partial sums in part[split]; the block that arrives LAST at the tile's counter adds the partials of all
+        // splits in split order (so the result does not depend on which block that is) and runs the whole
+        // epilogue — no second kernel, and the fused GroupNorm statistics keep the one-slice-per-M-tile layout of
+        // an unsplit conv. The producer waves have retired by now (a barrier counts live waves only).
+        // Visibility across the XCDs' L2s without a device-scope fence (a release fence writes the WHOLE L2 back:
+        // measured +22 us per conv): the partials are stored and loaded as relaxed device-scope atomics — write-
+        // through stores / loads that bypass the non-coherent cache levels (sc1) — and ordered against the counter
+        // by waiting for the stores' completion (s_waitcnt, i.e. a workgroup-scope release) before the barrier.
+        // Addresses: wave-uniform 64-bit base + one 32-bit lane offset (the partial buffer is far below 4 GiB).
+        const size_t MC = (size_t)M * Cout;
+        const unsigned lane_off = ((unsigned)(4 * lh) * (unsigned)Cout + (unsigned)li) * 4u;
+        const float *tile0 = p.part + (size_t)(m0 + wm * WM) * Cout + n0 + wn * WN;      // wave-uniform
+        auto elem = [&](int sp, int mi, int ni, int r) -> float * {
+            const float *ub = tile0 + (size_t)sp * MC + (size_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * Cout + ni * 32;
+            return reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(ub) + lane_off);
+        };
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(elem(split, mi, ni, r), acc[mi][ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // the stores have completed ...
+        __syncthreads();                            // ... in all four consumer waves, before the tile counts this block
+        int *last_flag = reinterpret_cast<int *>(smem) + NS * STAGE - 4;   // (far behind the statistics staging area)
+        if (threadIdx.x == 0) {
+            unsigned *cnt = p.tile_cnt + (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+            const unsigned arrived = atomicAdd(cnt, 1u);
+            const int last = arrived == (unsigned)(nsplit - 1);
+            if (last) *cnt = 0u;                    // ready for the next launch (nobody else touches it any more)
+            *last_flag = last;
+        }
+        __syncthreads();
+        if (*last_flag == 0) return;
+        // U splits x the whole accumulator tile in flight per round trip, added in split order
+        constexpr int U = 4 / (MI * NI);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int sp = 0; sp < nsplit; sp += U) {
+            float t[U][MI][NI][16];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            t[u][mi][ni][r] = __hip_atomic_load(elem(min(sp + u, nsplit - 1), mi, ni, r), __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (sp + u < nsplit) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[mi][ni][r] += t[u][mi][ni][r];
+                }
+        }
+        conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, 0, 1);
+        if (p.stats != nullptr) {                   // (the epilogue ended with a barrier behind the staged column sums)
+            const double2 *red = reinterpret_cast<const double2 *>(smem);
+            const int col = threadIdx.x;
+            if (col < BN) {
+                double a = 0, b = 0;
+#pragma unroll
+                for (int j = 0; j < WGM * 2; ++j) { const double2 t2 = red[j * BN + col]; a += t2.x; b += t2.y; }
+                const int n = m0 / HWo, slice = p.stats_slice0 + (m0 - n * HWo) / BM;
+                double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0 + col) * 2;
+                o[0] = a; o[1] = b;
+            }
+        }
+        return;
+    }
+    }
     conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, split, nsplit);
 }
 
@@ -1668,6 +1754,17 @@ int conv_splits(long M, int Cout, int Cin) {
     return s;
 }
 
+bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases) {
+    static const int off = getenv("SR3_NO_INPLACE_SPLIT") ? atoi(getenv("SR3_NO_INPLACE_SPLIT")) : 0;
+    if (off || conv_splits(M, Cout, Cin) <= 1) return false;
+    static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
+    const int t = conv_tile_choice(M, Cout);
+    const long tiles = ((M + bm[t] - 1) / bm[t]) * ((Cout + bn[t] - 1) / bn[t]);
+    // the 64x64-tile kernel only; whole tiles per image (the statistics slices are per M-tile of an image) and in N
+    // (nothing is masked in the fix-up), and a counter for every tile
+    return t == 2 && (HWo % bm[t]) == 0 && (Cout % bn[t]) == 0 && tiles * phases <= CONV_TILE_COUNTERS;
+}
+
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     if (p_in.up2) { launch_conv_up2(p_in, s); return; }     // weights must be in phase form (make_up2_phase_weights)
     ConvParams p = p_in;
@@ -1681,10 +1778,13 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         p.w_shift = lg(p.Wout);
     }
     if (p.part == nullptr) p.splits = 1;
-    // split-K: the blocks hold partial sums, the statistics come out of the reduce pass (one slice per TP pixels);
-    // they need whole tiles per image and at most 1024 channels, else the caller's statistics kernel runs
+    const bool inplace = p.splits > 1 && p.tile_cnt != nullptr &&
+                         conv_split_inplace(M, p.Hout * p.Wout, p.out.C, p.in0.C + (p.in1.p ? p.in1.C : 0), p.phases);
+    if (!inplace) p.tile_cnt = nullptr;
+    // split-K, two-kernel form: the blocks hold partial sums, the statistics come out of the reduce pass (one slice
+    // per TP pixels); they need whole tiles per image and at most 1024 channels, else the caller's statistics kernel runs
     double *reduce_stats = nullptr;
-    if (p.splits > 1) {
+    if (p.splits > 1 && !inplace) {
         const int HWo = p.Hout * p.Wout;
         if (p.stats && splitk_stats_slices(HWo, p.out.C) > 0) reduce_stats = p.stats;
         p.stats = nullptr;
@@ -1714,7 +1814,7 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         else launch_cfg<128, 128, 2, 2>(p, s);
         break;
     }
-    if (p.splits > 1) {
+    if (p.splits > 1 && !inplace) {
         const int HWo = p.Hout * p.Wout, TP = splitk_reduce_tp(HWo);
         p.stats = reduce_stats;
         if (reduce_stats) p.phase_slices = splitk_stats_slices(HWo, p.out.C);   // slices of one sub-pixel phase (phases > 1)

@@ -130,6 +130,7 @@ struct sr3_ctx {
     // split-f16 range check: kernels set *d_ovf when a value stored in the split format exceeds the
     // fp16 range (|v| > 65504); sr3_unet_forward / sr3_sample_end / sr3_range_check read it and fail
     int *d_ovf = nullptr, *h_ovf = nullptr;
+    unsigned *tile_cnt = nullptr;       // ConvParams::tile_cnt: arrival counters of the in-place split-K convs (zero between launches)
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -501,7 +502,9 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             const int hw = up ? (h * w) / 4 : h * w;
             const int bm = conv_tile_m((long)B * hw, oc);
             auto slices_for = [&](int cin) {
-                if (conv_splits((long)B * hw, oc, cin) > 1) return (up ? 4 : 1) * splitk_stats_slices(hw, oc);
+                // (an in-place split conv leaves the same slices as an unsplit one)
+                if (conv_splits((long)B * hw, oc, cin) > 1 && !conv_split_inplace((long)B * hw, hw, oc, cin, up ? 4 : 1))
+                    return (up ? 4 : 1) * splitk_stats_slices(hw, oc);
                 return (hw % bm == 0) ? (up ? 4 : 1) * (hw / bm) : 0;
             };
             s_out[i] = slices_for(m.kind == M_RES ? oc : m.conv.cin_pad);
@@ -656,6 +659,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
     p.splits = conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
     p.part = c->part;
+    p.tile_cnt = c->tile_cnt;
     p.ovf = c->d_ovf;
     if (cv2) {
         p.in2 = in2; p.in2b = in2b;
@@ -1044,6 +1048,8 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
     if (hipStreamCreate(&c->own_stream) != hipSuccess) { sr3_destroy(c); return fail("hipStreamCreate failed"); }
     c->stream = c->own_stream;
     if (hipMalloc(&c->d_ovf, sizeof(int)) != hipSuccess || hipMemset(c->d_ovf, 0, sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->tile_cnt, CONV_TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(c->tile_cnt, 0, CONV_TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_ovf), sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sr3_destroy(c);
         return fail("allocating the range-check flag failed");
@@ -1074,6 +1080,7 @@ void sr3_destroy(sr3_ctx *c) {
     if (c->d_nl) (void)hipFree(c->d_nl);
     drop_graphs(c);
     if (c->d_ovf) (void)hipFree(c->d_ovf);
+    if (c->tile_cnt) (void)hipFree(c->tile_cnt);
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     if (c->d_step) (void)hipFree(c->d_step);
@@ -1448,6 +1455,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
         if (p.splits > 1) {
             HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * p.splits * Mo * Cout * sizeof(float)));
             p.part = part;
+            p.tile_cnt = c->tile_cnt;
         }
     }
     hipEvent_t e0, e1, e2;

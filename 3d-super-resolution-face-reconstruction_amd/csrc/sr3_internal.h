@@ -75,6 +75,11 @@ struct ConvParams {
     // adds the partials and applies the epilogue. splits <= 1: single pass.
     int splits = 1;
     float *part = nullptr;
+    // in-place split-K (conv_split_inplace() tells when launch_conv uses it): one zero-initialised counter per
+    // output tile and sub-pixel phase; the last block to arrive at a tile adds the partials and runs the
+    // epilogue itself (no reduce kernel; fused statistics in the unsplit layout: one slice per M-tile).
+    // nullptr: always the two-kernel form.
+    unsigned *tile_cnt = nullptr;
     // split-f16 range check: any value stored in the split format (out_split) with |v| > 65504 (or
     // non-finite) sets *ovf = 1; the API call that ran the launch then fails (never a silent clamp)
     int *ovf = nullptr;
@@ -116,6 +121,10 @@ void make_up2_phase_weights(const float *packed9, int Cout, int CinPad, float *d
 int conv_tile_m(long M, int Cout);
 // number of K-splits launch_conv wants for this problem (1 = none); Cin per tap, multiple of 32
 int conv_splits(long M, int Cout, int Cin);
+// true when a split conv of this shape adds its partials in place (ConvParams::tile_cnt given): its fused statistics
+// then have the unsplit layout, HWo / conv_tile_m() slices per image; HWo = pixels of one image (and phase)
+bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases = 1);
+constexpr int CONV_TILE_COUNTERS = 8192;    // capacity of ConvParams::tile_cnt (tiles x phases of one launch)
 // a split conv's fused GroupNorm statistics come out of its reduce pass: slices per image (and per
 // sub-pixel phase) for an output of HWo pixels; the caller sizes / strides ConvParams::stats with it
 // (0: not available for this shape)
