@@ -399,14 +399,15 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
     constexpr int TAPS = KS * KS;
-    // split-K: this block reduces chunks [cb, ce) of the input channels (all taps); the fused 1x1
-    // term belongs to the last split
+    // split-K: this block reduces chunks [cb, ce) of the input channels (all taps) and chunks [c2b, c2e) of the
+    // fused 1x1 term (res_conv) — both divided, so the splits carry equal numbers of K-steps
     const int split = blockIdx.y, nsplit = gridDim.y;
     const int nchunk = Cin / BK;
     const int cb = (int)((long)nchunk * split / nsplit) * BK, ce = (int)((long)nchunk * (split + 1) / nsplit) * BK;
     const int C2a = p.in2.p ? p.in2.C : 0, C2t = C2a + (p.in2b.p ? p.in2b.C : 0);
-    const int C2 = split == nsplit - 1 ? C2t : 0;                            // fused 1x1 term (res_conv)
-    const int nk = TAPS * ((ce - cb) / BK) + C2 / BK;
+    const int nchunk2 = C2t / BK;
+    const int c2b = (int)((long)nchunk2 * split / nsplit) * BK, c2e = (int)((long)nchunk2 * (split + 1) / nsplit) * BK;
+    const int nk = TAPS * ((ce - cb) / BK) + (c2e - c2b) / BK;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -460,8 +461,8 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             const int n = div_hw(p, m, HWo);
             const int rem = m - n * HWo;
             const int oy = div_w(p, rem, p.Wout);
-            vA2[i] = C2 ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)C2a * 4u + schunk16 : 0u;
-            vA2b[i] = C2 > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * p.Wout) * (unsigned)(C2t - C2a) * 4u + schunk16 : 0u;
+            vA2[i] = C2t ? (unsigned)p.in2.pix(n, oy, rem - oy * p.Wout) * (unsigned)C2a * 4u + schunk16 : 0u;
+            vA2b[i] = C2t > C2a ? (unsigned)p.in2b.pix(n, oy, rem - oy * p.Wout) * (unsigned)(C2t - C2a) * 4u + schunk16 : 0u;
         });
         const size_t tapstride = (size_t)Cout * Cin;   // floats between taps of the packed weights
 
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             });
         }
         // fused 1x1 term: K-steps over the channels of in2, read at the output pixel
-        for (int c0 = 0; c0 < C2; c0 += BK) {
+        for (int c0 = c2b; c0 < c2e; c0 += BK) {
             float *Ad = smem + (k % NS) * STAGE + w * 256;
             float *Bd = Ad + BM * ROWF;
             const bool first2 = c0 < C2a;
@@ -1748,9 +1749,16 @@ int conv_splits(long M, int Cout, int Cin) {
     const int t = conv_tile_choice(M, Cout);
     const long tiles = ((M + bm[t] - 1) / bm[t]) * ((Cout + bn[t] - 1) / bn[t]);
     const int nchunk = Cin / BK;
-    if (tiles >= 128 || nchunk < 4) return 1;
+    // (tuned on B = 1 at 128x128 and config 1, with the in-place fix-up: profiles/README.md finding 42)
+    int tmin = 256, target = 256, chmin = 2;
+#ifdef SR3_EXPERIMENTS
+    if (const char *e = getenv("SR3_SPLIT_TMIN")) tmin = atoi(e);
+    if (const char *e = getenv("SR3_SPLIT_TARGET")) target = atoi(e);
+    if (const char *e = getenv("SR3_SPLIT_CHMIN")) chmin = atoi(e);
+#endif
+    if (tiles >= tmin || nchunk < 2 * chmin) return 1;
     int s = 2;
-    while (s * 2 <= nchunk / 2 && tiles * s * 2 <= 512 && s < 16) s *= 2;
+    while (s * 2 <= nchunk / chmin && tiles * s * 2 <= target && s < 16) s *= 2;
     return s;
 }
 
