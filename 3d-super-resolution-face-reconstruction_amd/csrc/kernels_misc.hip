@@ -705,12 +705,15 @@ __global__ __launch_bounds__(256) void attention_vt_kernel(const float *__restri
     for (int g = 0; g < 4; ++g) *reinterpret_cast<h16x8 *>(dst + g * 16) = o[g];
 }
 
-// NTW / NTC: key tiles (scores) and channel tiles (P v) per wave, compile-time maxima
-template <int NTW, int NTC>
-__global__ __launch_bounds__(256) void attention_split_kernel(const float *__restrict__ qkv, const float *__restrict__ vt,
+// NTW / NTC: key tiles (scores) and channel tiles (P v) per wave, compile-time maxima; MTQ: 16-query tiles per block
+// (32 or 64 queries); NWAVES: waves per block. 64 queries x 8 waves halves the k / v^T bytes a block pulls through
+// L2 per query (the kernel is bound by that traffic) at the same number of waves per CU.
+template <int NTW, int NTC, int MTQ, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const float *__restrict__ qkv, const float *__restrict__ vt,
                                                               int N, int C, float *__restrict__ out,
                                                               float *__restrict__ out_split, int *ovf, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) float S[];   // [32][ld]: fp32 scores, then P as [hi8|lo8] groups
+    extern __shared__ __attribute__((aligned(16))) float S[];   // [QB][ld]: fp32 scores, then P as [hi8|lo8] groups
+    constexpr int QB = MTQ * 16;
 #ifndef SR3_EXPERIMENTS
     dbg = 0;        // timing experiments only (SR3_ATTN_DBG in the experiments build): 1 no scores, 2 no softmax, 4 no P v
 #endif
@@ -724,8 +727,8 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
         const int nwg = gridDim.x, xcd = bid & 7, loc = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
     }
-    const int nqb = Np / 32;
-    const int b = bid / nqb, q0 = (bid - b * nqb) * 32;
+    const int nqb = Np / QB;
+    const int b = bid / nqb, q0 = (bid - b * nqb) * QB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l16 = lane & 15, q4 = lane >> 4;
     const size_t rsb = (size_t)3 * C * 4;                        // bytes per token row
@@ -736,29 +739,29 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
     // ---- scores: S[query][key] = q . k / sqrt(C). Wave w owns the key tiles w * NTW .. + NTW - 1: the q
     // fragments of a channel chunk are loaded once for all of them ----
     {
-        const char *qrow[2];
+        const char *qrow[MTQ];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) qrow[mt] = base + (size_t)min(q0 + mt * 16 + l16, N - 1) * rsb + q4 * 16;
+        for (int mt = 0; mt < MTQ; ++mt) qrow[mt] = base + (size_t)min(q0 + mt * 16 + l16, N - 1) * rsb + q4 * 16;
         const int nkt = Np / 16;                                  // key tiles
         const char *krow[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
             krow[i] = base + (size_t)min((wid * NTW + i) * 16 + l16, N - 1) * rsb + (size_t)nch * 128 + q4 * 16;
-        f32x4a acc[NTW][2];
+        f32x4a acc[NTW][MTQ];
 #pragma unroll
         for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][mt][r] = 0.f;
         if (wid * NTW < nkt && !(dbg & 1)) {
             // the fragments of chunk ch + 1 are in flight while chunk ch multiplies (two register sets; rows of
             // tiles past the end are clamped duplicates whose scores are never stored)
-            h16x8 ah[2][2], al[2][2], bh[2][NTW], bl[2][NTW];
+            h16x8 ah[2][MTQ], al[2][MTQ], bh[2][NTW], bl[2][NTW];
             auto fetch = [&](auto setc, int ch) {
                 constexpr int set = decltype(setc)::value;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MTQ; ++mt) {
                     ah[set][mt] = *reinterpret_cast<const h16x8 *>(qrow[mt] + ch * 128);
                     al[set][mt] = *reinterpret_cast<const h16x8 *>(qrow[mt] + ch * 128 + 64);
                 }
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
 #pragma unroll
                 for (int i = 0; i < NTW; ++i)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MTQ; ++mt) {
                         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[set][mt], bh[set][i], acc[i][mt], 0, 0, 0);
                         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][mt], bl[set][i], acc[i][mt], 0, 0, 0);
                         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][mt], bh[set][i], acc[i][mt], 0, 0, 0);
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
             if (kt < nkt) {
                 const int col = kt * 16 + l16;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         S[(mt * 16 + 4 * q4 + j) * ld + col] = (col < N) ? acc[i][mt][j] / sdiv : -INFINITY;
@@ -807,56 +810,67 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
 
     // ---- softmax over keys (fp32, 8 lanes per query row), then P -> [8 hi halfs | 8 lo halfs] per 8 keys, in place ----
     if (!(dbg & 2)) {
-        const int row = tid >> 3, sub = tid & 7;
-        float *sr = S + row * ld;
-        float mx = -INFINITY;
-        for (int c = sub; c < Np; c += 8) mx = fmaxf(mx, sr[c]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
-        mx = fmaxf(mx, __shfl_xor(mx, 2));
-        mx = fmaxf(mx, __shfl_xor(mx, 4));
-        float sum = 0.f;
-        for (int c = sub; c < Np; c += 8) {
-            const float e = expf(sr[c] - mx);
-            sr[c] = e;
-            sum += e;
-        }
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        sum += __shfl_xor(sum, 4);
-        __syncthreads();                    // every lane of the row has finished its strided pass
-        for (int g = sub; g < Np / 8; g += 8) {
-            float *gp = sr + g * 8;
-            const f32x4a v0 = *reinterpret_cast<const f32x4a *>(gp), v1 = *reinterpret_cast<const f32x4a *>(gp + 4);
-            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            h16x8 hi, lo;
+        constexpr int RPP = NWAVES * 8, NRP = QB / RPP;     // query rows per pass of the block, passes
+        const int sub = tid & 7;
+        float sums[NRP];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float pv = f[j] / sum;
-                hi[j] = (_Float16)pv;
-                lo[j] = (_Float16)(pv - (float)hi[j]);
+        for (int rp = 0; rp < NRP; ++rp) {
+            float *sr = S + ((tid >> 3) + rp * RPP) * ld;
+            float mx = -INFINITY;
+            for (int c = sub; c < Np; c += 8) mx = fmaxf(mx, sr[c]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 4));
+            float sum = 0.f;
+            for (int c = sub; c < Np; c += 8) {
+                const float e = expf(sr[c] - mx);
+                sr[c] = e;
+                sum += e;
             }
-            *reinterpret_cast<h16x8 *>(gp) = hi;
-            *reinterpret_cast<h16x8 *>(gp + 4) = lo;
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 4);
+            sums[rp] = sum;
+        }
+        __syncthreads();                    // every lane of a row has finished its strided pass
+#pragma unroll
+        for (int rp = 0; rp < NRP; ++rp) {
+            float *sr = S + ((tid >> 3) + rp * RPP) * ld;
+            const float sum = sums[rp];
+            for (int g = sub; g < Np / 8; g += 8) {
+                float *gp = sr + g * 8;
+                const f32x4a v0 = *reinterpret_cast<const f32x4a *>(gp), v1 = *reinterpret_cast<const f32x4a *>(gp + 4);
+                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                h16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = f[j] / sum;
+                    hi[j] = (_Float16)pv;
+                    lo[j] = (_Float16)(pv - (float)hi[j]);
+                }
+                *reinterpret_cast<h16x8 *>(gp) = hi;
+                *reinterpret_cast<h16x8 *>(gp + 4) = lo;
+            }
         }
     }
     __syncthreads();
 
     // ---- out = P v: A = P rows from LDS, B = rows of v^T (8 consecutive keys per lane and channel); wave w
-    // owns the channel tiles w, w + 4, ... ----
+    // owns the channel tiles w, w + NWAVES, ... ----
     const unsigned psel = split_pair_selector(l16 & 1);
     unsigned range_bits = 0;
     const int nct = C >> 4, nks = Np >> 5;
     const char *vrow[NTC];
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
-        const int c = min((wid + 4 * t) * 16 + l16, C - 1);
+        const int c = min((wid + NWAVES * t) * 16 + l16, C - 1);
         vrow[t] = reinterpret_cast<const char *>(vt) + ((size_t)b * C + c) * nks * 128 + q4 * 16;
     }
-    f32x4a acc[NTC][2];
+    f32x4a acc[NTC][MTQ];
 #pragma unroll
     for (int t = 0; t < NTC; ++t)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][mt][r] = 0.f;
     {
@@ -873,9 +887,9 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
         };
         auto mult = [&](auto setc, int ks) {
             constexpr int set = decltype(setc)::value;
-            h16x8 ah[2], al[2];
+            h16x8 ah[MTQ], al[MTQ];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MTQ; ++mt) {
                 const float *pp = S + (mt * 16 + l16) * ld + (ks * 4 + q4) * 8;
                 ah[mt] = *reinterpret_cast<const h16x8 *>(pp);
                 al[mt] = *reinterpret_cast<const h16x8 *>(pp + 4);
@@ -883,7 +897,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
 #pragma unroll
             for (int t = 0; t < NTC; ++t)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MTQ; ++mt) {
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], vh[set][t], acc[t][mt], 0, 0, 0);
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vl[set][t], acc[t][mt], 0, 0, 0);
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vh[set][t], acc[t][mt], 0, 0, 0);
@@ -902,10 +916,10 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float *__res
     // C/D map: col = l16 (channel), row = 4 q4 + j (query)
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
-        const int ch0 = (wid + 4 * t) * 16;
-        if (wid + 4 * t < nct) {
+        const int ch0 = (wid + NWAVES * t) * 16;
+        if (wid + NWAVES * t < nct) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = q0 + mt * 16 + 4 * q4 + j;
@@ -934,26 +948,35 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
                               int *ovf, hipStream_t s) {
     const int Np = (N + 31) & ~31;
     hipLaunchKernelGGL(attention_vt_kernel, dim3(Np / 32, (C + 127) / 128, B), dim3(256), 0, s, qkv_split, N, C, vt);
-    const size_t lds = (size_t)32 * (Np + 8) * sizeof(float);
-    const int ntw = (Np / 16 + 3) / 4, ntc = (C / 16 + 3) / 4;
+    // 64 queries x 8 waves per block where that still leaves a block for every CU (config 3: B = 64, 256 tokens);
+    // else 32 queries x 4 waves
+    static const int q64 = getenv("SR3_ATTN_Q64") ? atoi(getenv("SR3_ATTN_Q64")) : 1;
+    const bool big = q64 && (Np % 64) == 0 && (long)B * (Np / 64) >= 256 && (Np / 16 + 7) / 8 <= 4 && (C / 16 + 7) / 8 <= 4;
+    const int QB = big ? 64 : 32, NW = big ? 8 : 4;
+    const size_t lds = (size_t)QB * (Np + 8) * sizeof(float);
+    const int ntw = (Np / 16 + NW - 1) / NW, ntc = (C / 16 + NW - 1) / NW;
     int dbg = 0;
 #ifdef SR3_EXPERIMENTS
     if (const char *e = getenv("SR3_ATTN_DBG")) dbg = atoi(e);
 #endif
-#define SR3_AT(A, B_)                                                                                              \
+#define SR3_AT(A, B_, MQ, W_)                                                                                      \
     {                                                                                                              \
         static size_t attr = 0;                                                                                    \
         if (lds > attr) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<A, B_>),               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<A, B_, MQ, W_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
             attr = lds;                                                                                            \
         }                                                                                                          \
-        hipLaunchKernelGGL((attention_split_kernel<A, B_>), dim3((Np / 32) * B), dim3(256), lds, s, qkv_split, vt, N, C, out, \
-                           out_split, ovf, dbg);                                                                   \
+        hipLaunchKernelGGL((attention_split_kernel<A, B_, MQ, W_>), dim3((Np / QB) * B), dim3(W_ * 64), lds, s, qkv_split, vt, \
+                           N, C, out, out_split, ovf, dbg);                                                        \
     }
-    if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2)
-    else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8)
-    else SR3_AT(8, 8)
+    if (big) {
+        if (ntw <= 2 && ntc <= 4) SR3_AT(2, 4, 4, 8)
+        else SR3_AT(4, 4, 4, 8)
+    }
+    else if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2, 2, 4)
+    else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8, 2, 4)
+    else SR3_AT(8, 8, 2, 4)
 #undef SR3_AT
     return 4.0 * (double)B * N * N * C;
 }

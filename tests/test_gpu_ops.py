@@ -121,9 +121,10 @@ def test_groupnorm_affine(eng, shape):
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("B,N,C", [(2, 64, 512), (1, 256, 512), (3, 1, 64), (2, 4, 32), (2, 100, 64), (1, 16, 512),
-                                   (3, 256, 64), (1, 1024, 32)])
+                                   (3, 256, 64), (1, 1024, 32), (64, 256, 64), (128, 128, 96)])
 def test_attention(eng, B, N, C, prec):
-    """f32: f32-MFMA core; f16x3: the split-f16 core (q, k, v and the probabilities as hi + lo halfs)."""
+    """f32: f32-MFMA core; f16x3: the split-f16 core (q, k, v and the probabilities as hi + lo halfs); the last two
+    shapes have 256+ blocks of 64 queries: the 64-query x 8-wave form of the split core (BASELINE config 3 at B = 64)."""
     rs = np.random.RandomState(B * 1000 + N + C)
     qkv = _rand(rs, B, N, 3 * C)
     eng.set_precision(prec)
