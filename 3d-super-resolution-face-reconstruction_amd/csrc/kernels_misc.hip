@@ -665,6 +665,43 @@ namespace {
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+// compile-time loop (register arrays indexed by the loop variable stay in registers)
+template <int N, typename F>
+__device__ __forceinline__ void attn_static_for(F &&f) {
+    if constexpr (N > 0) {
+        attn_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Operand ring of NSET register sets over n steps: the fragments of steps i + 1 .. i + NSET - 1 are in flight while
+// step i multiplies. fetch(set, step), mult(set, step). (Deeper than two sets did not pay: profiles/README.md 43.)
+template <int NSET, typename FE, typename MU>
+__device__ __forceinline__ void attn_ring(int n, FE &&fetch, MU &&mult) {
+    if constexpr (NSET == 2) {
+        fetch(std::integral_constant<int, 0>{}, 0);
+        for (int c = 0; c < n; c += 2) {
+            fetch(std::integral_constant<int, 1>{}, min(c + 1, n - 1));
+            mult(std::integral_constant<int, 0>{}, c);
+            if (c + 1 < n) {
+                fetch(std::integral_constant<int, 0>{}, min(c + 2, n - 1));
+                mult(std::integral_constant<int, 1>{}, c + 1);
+            }
+        }
+        return;
+    }
+    attn_static_for<NSET - 1>([&](auto sc) { fetch(sc, min((int)decltype(sc)::value, n - 1)); });
+    for (int c = 0; c < n; c += NSET) {
+        attn_static_for<NSET>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (c + u < n) {
+                fetch(std::integral_constant<int, (u + NSET - 1) % NSET>{}, min(c + u + NSET - 1, n - 1));
+                mult(uc, c + u);
+            }
+        });
+    }
+}
+
 // v^T in the split format: vt[b][c][Np / 32 chunks][32 hi halfs of keys | 32 lo halfs] from the token-major
 // v part of qkv (one LDS transpose per 32 keys x 128 channels; done once per image, not once per block of
 // queries). Keys >= N are clamped (their probabilities are 0).
@@ -736,12 +773,44 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
     const float sdiv = sqrtf((float)C);
     const int nch = C >> 5;
 
+    // ---- 64-query form: the q rows of the block are staged in LDS once (every wave needs the fragments of all
+    // queries: read from global memory they were half of the bytes a block pulled through L2). Row stride
+    // 4 C + 32 bytes: the 16-byte fragment reads of a lane group fall on distinct banks. The score tile S takes
+    // over the same LDS region once the scores are in registers. ----
+    constexpr bool QLDS = MTQ == 4;
+    constexpr int NSET = 2;     // register sets of the operand rings (4 sets in the 64-query form: 240 registers, 0.487 vs 0.473 ms per step)
+    const int qstride = C * 4 + 32;
+    if (QLDS) {
+        char *Q = reinterpret_cast<char *>(S);
+        const int pieces = C >> 2;                                  // 16-byte pieces per q row (4 C bytes)
+        for (int it = tid; it < QB * pieces; it += NWAVES * 64 * 4) {
+            f32x4a v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(it + u * NWAVES * 64, QB * pieces - 1);
+                const int r = e / pieces, pc = e - r * pieces;
+                v[u] = *reinterpret_cast<const f32x4a *>(base + (size_t)min(q0 + r, N - 1) * rsb + pc * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = it + u * NWAVES * 64;
+                if (e < QB * pieces) {
+                    const int r = e / pieces, pc = e - r * pieces;
+                    *reinterpret_cast<f32x4a *>(Q + r * qstride + pc * 16) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
     // ---- scores: S[query][key] = q . k / sqrt(C). Wave w owns the key tiles w * NTW .. + NTW - 1: the q
     // fragments of a channel chunk are loaded once for all of them ----
     {
         const char *qrow[MTQ];
 #pragma unroll
-        for (int mt = 0; mt < MTQ; ++mt) qrow[mt] = base + (size_t)min(q0 + mt * 16 + l16, N - 1) * rsb + q4 * 16;
+        for (int mt = 0; mt < MTQ; ++mt)
+            qrow[mt] = QLDS ? reinterpret_cast<const char *>(S) + (mt * 16 + l16) * qstride + q4 * 16
+                            : base + (size_t)min(q0 + mt * 16 + l16, N - 1) * rsb + q4 * 16;
         const int nkt = Np / 16;                                  // key tiles
         const char *krow[NTW];
 #pragma unroll
@@ -757,7 +826,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
         if (wid * NTW < nkt && !(dbg & 1)) {
             // the fragments of chunk ch + 1 are in flight while chunk ch multiplies (two register sets; rows of
             // tiles past the end are clamped duplicates whose scores are never stored)
-            h16x8 ah[2][MTQ], al[2][MTQ], bh[2][NTW], bl[2][NTW];
+            h16x8 ah[NSET][MTQ], al[NSET][MTQ], bh[NSET][NTW], bl[NSET][NTW];
             auto fetch = [&](auto setc, int ch) {
                 constexpr int set = decltype(setc)::value;
 #pragma unroll
@@ -771,7 +840,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                     bl[set][i] = *reinterpret_cast<const h16x8 *>(krow[i] + ch * 128 + 64);
                 }
             };
-            auto mult = [&](auto setc) {
+            auto mult = [&](auto setc, int) {
                 constexpr int set = decltype(setc)::value;
 #pragma unroll
                 for (int i = 0; i < NTW; ++i)
@@ -782,16 +851,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][mt], bh[set][i], acc[i][mt], 0, 0, 0);
                     }
             };
-            fetch(std::integral_constant<int, 0>{}, 0);
-            for (int ch = 0; ch < nch; ch += 2) {               // C is a multiple of 32; odd chunk counts re-fetch the last one
-                fetch(std::integral_constant<int, 1>{}, min(ch + 1, nch - 1));
-                mult(std::integral_constant<int, 0>{});
-                if (ch + 1 < nch) {
-                    fetch(std::integral_constant<int, 0>{}, min(ch + 2, nch - 1));
-                    mult(std::integral_constant<int, 1>{});
-                }
-            }
+            attn_ring<NSET>(nch, fetch, mult);      // (steps past the end re-fetch the last chunk: unused)
         }
+        if (QLDS) __syncthreads();          // every wave has read its last q fragment: S may overwrite the q rows
         // C/D map: col = l16 (key), row = 4 q4 + j (query)
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
@@ -876,7 +938,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
     {
         // v^T fragments of key step ks + 1 in flight while step ks multiplies (channel tiles past the end are
         // clamped duplicates that are never stored)
-        h16x8 vh[2][NTC], vl[2][NTC];
+        h16x8 vh[NSET][NTC], vl[NSET][NTC];
         auto fetch = [&](auto setc, int ks) {
             constexpr int set = decltype(setc)::value;
 #pragma unroll
@@ -903,15 +965,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vh[set][t], acc[t][mt], 0, 0, 0);
                 }
         };
-        fetch(std::integral_constant<int, 0>{}, 0);
-        for (int ks = 0; ks < ((dbg & 4) ? 0 : nks); ks += 2) {
-            fetch(std::integral_constant<int, 1>{}, min(ks + 1, nks - 1));
-            mult(std::integral_constant<int, 0>{}, ks);
-            if (ks + 1 < nks) {
-                fetch(std::integral_constant<int, 0>{}, min(ks + 2, nks - 1));
-                mult(std::integral_constant<int, 1>{}, ks + 1);
-            }
-        }
+        if (!(dbg & 4)) attn_ring<NSET>(nks, fetch, mult);
     }
     // C/D map: col = l16 (channel), row = 4 q4 + j (query)
 #pragma unroll
@@ -951,9 +1005,9 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
     // 64 queries x 8 waves per block where that still leaves a block for every CU (config 3: B = 64, 256 tokens);
     // else 32 queries x 4 waves
     static const int q64 = getenv("SR3_ATTN_Q64") ? atoi(getenv("SR3_ATTN_Q64")) : 1;
-    const bool big = q64 && (Np % 64) == 0 && (long)B * (Np / 64) >= 256 && (Np / 16 + 7) / 8 <= 4 && (C / 16 + 7) / 8 <= 4;
+    const bool big = q64 && (Np % 64) == 0 && (long)B * (Np / 64) >= 256 && (Np / 16 + 7) / 8 <= 2 && (C / 16 + 7) / 8 <= 4;
     const int QB = big ? 64 : 32, NW = big ? 8 : 4;
-    const size_t lds = (size_t)QB * (Np + 8) * sizeof(float);
+    const size_t lds = std::max((size_t)QB * (Np + 8) * sizeof(float), big ? (size_t)QB * (C * 4 + 32) : (size_t)0);
     const int ntw = (Np / 16 + NW - 1) / NW, ntc = (C / 16 + NW - 1) / NW;
     int dbg = 0;
 #ifdef SR3_EXPERIMENTS
@@ -970,10 +1024,7 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
         hipLaunchKernelGGL((attention_split_kernel<A, B_, MQ, W_>), dim3((Np / QB) * B), dim3(W_ * 64), lds, s, qkv_split, vt, \
                            N, C, out, out_split, ovf, dbg);                                                        \
     }
-    if (big) {
-        if (ntw <= 2 && ntc <= 4) SR3_AT(2, 4, 4, 8)
-        else SR3_AT(4, 4, 4, 8)
-    }
+    if (big) SR3_AT(2, 4, 4, 8)       // (at most 256 tokens: 2 key tiles per wave; 240 registers with the 4-set rings)
     else if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2, 2, 4)
     else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8, 2, 4)
     else SR3_AT(8, 8, 2, 4)
