@@ -665,40 +665,19 @@ namespace {
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
-// compile-time loop (register arrays indexed by the loop variable stay in registers)
-template <int N, typename F>
-__device__ __forceinline__ void attn_static_for(F &&f) {
-    if constexpr (N > 0) {
-        attn_static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-
-// Operand ring of NSET register sets over n steps: the fragments of steps i + 1 .. i + NSET - 1 are in flight while
-// step i multiplies. fetch(set, step), mult(set, step). (Deeper than two sets did not pay: profiles/README.md 43.)
-template <int NSET, typename FE, typename MU>
-__device__ __forceinline__ void attn_ring(int n, FE &&fetch, MU &&mult) {
-    if constexpr (NSET == 2) {
-        fetch(std::integral_constant<int, 0>{}, 0);
-        for (int c = 0; c < n; c += 2) {
-            fetch(std::integral_constant<int, 1>{}, min(c + 1, n - 1));
-            mult(std::integral_constant<int, 0>{}, c);
-            if (c + 1 < n) {
-                fetch(std::integral_constant<int, 0>{}, min(c + 2, n - 1));
-                mult(std::integral_constant<int, 1>{}, c + 1);
-            }
+// Operand ring of two register sets over n steps: the fragments of step i + 1 are in flight while step i multiplies
+// (steps past the end re-fetch the last one: unused). fetch(set, step), mult(set, step). Four sets were tried in the
+// 64-query form (240 registers): 0.487 against 0.473 ms per step (profiles/README.md finding 43).
+template <typename FE, typename MU>
+__device__ __forceinline__ void attn_ring2(int n, FE &&fetch, MU &&mult) {
+    fetch(std::integral_constant<int, 0>{}, 0);
+    for (int c = 0; c < n; c += 2) {
+        fetch(std::integral_constant<int, 1>{}, min(c + 1, n - 1));
+        mult(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < n) {
+            fetch(std::integral_constant<int, 0>{}, min(c + 2, n - 1));
+            mult(std::integral_constant<int, 1>{}, c + 1);
         }
-        return;
-    }
-    attn_static_for<NSET - 1>([&](auto sc) { fetch(sc, min((int)decltype(sc)::value, n - 1)); });
-    for (int c = 0; c < n; c += NSET) {
-        attn_static_for<NSET>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            if (c + u < n) {
-                fetch(std::integral_constant<int, (u + NSET - 1) % NSET>{}, min(c + u + NSET - 1, n - 1));
-                mult(uc, c + u);
-            }
-        });
     }
 }
 
@@ -778,7 +757,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
     // 4 C + 32 bytes: the 16-byte fragment reads of a lane group fall on distinct banks. The score tile S takes
     // over the same LDS region once the scores are in registers. ----
     constexpr bool QLDS = MTQ == 4;
-    constexpr int NSET = 2;     // register sets of the operand rings (4 sets in the 64-query form: 240 registers, 0.487 vs 0.473 ms per step)
+    constexpr int NSET = 2;     // register sets of the operand rings
     const int qstride = C * 4 + 32;
     if (QLDS) {
         char *Q = reinterpret_cast<char *>(S);
@@ -851,7 +830,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[set][mt], bh[set][i], acc[i][mt], 0, 0, 0);
                     }
             };
-            attn_ring<NSET>(nch, fetch, mult);      // (steps past the end re-fetch the last chunk: unused)
+            attn_ring2(nch, fetch, mult);
         }
         if (QLDS) __syncthreads();          // every wave has read its last q fragment: S may overwrite the q rows
         // C/D map: col = l16 (key), row = 4 q4 + j (query)
@@ -965,7 +944,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vh[set][t], acc[t][mt], 0, 0, 0);
                 }
         };
-        if (!(dbg & 4)) attn_ring<NSET>(nks, fetch, mult);
+        if (!(dbg & 4)) attn_ring2(nks, fetch, mult);
     }
     // C/D map: col = l16 (channel), row = 4 q4 + j (query)
 #pragma unroll
