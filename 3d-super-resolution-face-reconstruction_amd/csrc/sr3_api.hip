@@ -1400,12 +1400,24 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
     p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
     if (resid_dev) p.resid = unpadded(const_cast<float *>(resid_dev), Cout, p.Hout, p.Wout);
+    // split-K exactly as the engine would choose it for this problem (in place or conv + reduce kernel)
+    float *part = nullptr;
+    {
+        const long Mo = (long)B * (up2 ? Hin * Win : p.Hout * p.Wout);
+        p.splits = conv_splits(Mo, Cout, Cin);
+        if (p.splits > 1) {
+            HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * p.splits * Mo * Cout * sizeof(float)));
+            p.part = part;
+            p.tile_cnt = c->tile_cnt;
+        }
+    }
     if (up2) launch_conv_up2(p, c->stream);
     else launch_conv(p, c->stream);
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipFree(dw));
     HIP_OK(hipFree(act));
     if (db) HIP_OK(hipFree(db));
+    if (part) HIP_OK(hipFree(part));
     HIP_OK(hipGetLastError());
     return c->prec ? range_check(c, "sr3_op_conv2d") : 0;
 }

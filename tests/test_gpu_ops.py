@@ -43,6 +43,13 @@ CONV_CASES = [
     (64, 32, 32, 128, 0, 128, 3, 1, False),   # 128x128 halo tile
     (64, 8, 8, 512, 0, 512, 3, 1, False),     # small M, deep K (the 8x8 level): 64x64 tile, 4-stage ring
     (64, 16, 16, 256, 0, 256, 3, 2, False),   # Downsample at full batch
+    # split-K shapes (few tiles, deep K: small batches)
+    (1, 8, 8, 512, 0, 512, 3, 1, False),      # one M-tile, 8 N-tiles: in-place split-K (whole tiles per image)
+    (1, 16, 16, 256, 256, 256, 3, 1, False),  # in place, concatenated input, 4 M-tiles
+    (4, 4, 4, 256, 0, 256, 3, 1, False),      # a tile spans four images: conv + reduce kernel
+    (2, 2, 2, 512, 0, 512, 3, 1, False),      # ragged M tile (8 pixels): conv + reduce kernel
+    (1, 8, 8, 256, 0, 256, 3, 1, True),       # Upsample phases with split-K (4 phases x in-place tiles)
+    (3, 8, 8, 256, 0, 768, 1, 1, False),      # 1x1 (attention qkv) with split-K, three M-tiles
 ]
 
 
