@@ -82,6 +82,19 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// The same with the address in the instruction's own (SGPR base) + (32-bit VGPR offset) form. Both halves are made
+// opaque to the optimiser at the point of use: left visible, base + zext(offset) is reassociated, tap-invariant
+// 64-bit sums are hoisted as VGPR pairs (18 pairs in the unrolled 3x3 loop) and every DMA pays a 64-bit vector
+// add; vector instructions of the producer waves compete with the consumers' MFMAs for issue (same box:
+// 17.45 -> 17.18 ms per B = 64 step for the weight tiles alone, profiles/README.md finding 48).
+__device__ __forceinline__ void dma16s(const char *sbase, unsigned voff, float *lds_wave_base) {
+#ifndef SR3_NO_OPAQUE_BASE
+    asm volatile("" : "+s"(sbase));
+    asm volatile("" : "+v"(voff));
+#endif
+    dma16(reinterpret_cast<const float *>(sbase + voff), lds_wave_base);
+}
+
 // KS: 1 | 2 | 3 (the tap loop is unrolled); nearest x2 upsampling never reaches the kernel (launch_conv_up2)
 // m / (Hout*Wout) and rem / Wout of the tile address set-up: shifts when the sizes are powers of two
 __device__ __forceinline__ int div_hw(const ConvParams &p, int m, int HWo) { return p.hw_shift >= 0 ? (m >> p.hw_shift) : m / HWo; }
@@ -483,15 +496,21 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                 if (!(SR3_DBG(p) & 1) || k == 0) {
                     const char *ab = abase + (size_t)(dy * Wp + dx) * Cs * 4;
                     if (SR3_DBG(p) & 2) ab = reinterpret_cast<const char *>(p.in0.p);   // experiment: cache-hot source
-                    static_for<AR>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        const unsigned vo = first ? vA0[i] : vA1[i];
-                        dma16(reinterpret_cast<const float *>(ab + vo), Ad + i * 1024);
-                    });
+                    if (first) {
+                        static_for<AR>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            dma16s(ab, vA0[i], Ad + i * 1024);
+                        });
+                    } else {
+                        static_for<AR>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            dma16s(ab, vA1[i], Ad + i * 1024);
+                        });
+                    }
                     const char *wb = (SR3_DBG(p) & 2) ? reinterpret_cast<const char *>(p.w) : wbase + (size_t)tap * tapstride * 4;
                     static_for<BR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                        dma16s(wb, vB[i], Bd + i * 1024);
                     });
                 }
                 if (k >= NS - 2) producer_sync<(NS - 2) * (AR + BR)>();
@@ -505,13 +524,20 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             const bool first2 = c0 < C2a;
             const char *ab = reinterpret_cast<const char *>(first2 ? p.in2.p + c0 : p.in2b.p + (c0 - C2a));
             const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
-            static_for<AR>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(ab + (first2 ? vA2[i] : vA2b[i])), Ad + i * 1024);
-            });
+            if (first2) {
+                static_for<AR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16s(ab, vA2[i], Ad + i * 1024);
+                });
+            } else {
+                static_for<AR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16s(ab, vA2b[i], Ad + i * 1024);
+                });
+            }
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
+                dma16s(wb, vB2[i], Bd + i * 1024);
             });
             if (k >= NS - 2) producer_sync<(NS - 2) * (AR + BR)>();
             ++k;
@@ -857,11 +883,18 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         const char *ab_ = reinterpret_cast<const char *>((first_ ? p.in0.p : p.in1.p) + (first_ ? c0a_ : c0a_ - C0)) + \
                           (size_t)(DY) * Wp * Cs_ * 4;                                             \
         float *Ad_ = Aring + (ga & 1) * ASTG + w * 256;                                            \
-        static_for<ARH>([&](auto ic) {                                                             \
-            constexpr int i = decltype(ic)::value;                                                 \
-            if ((4 * i + w) * 8 < rows_a)                                                          \
-                dma16(reinterpret_cast<const float *>(ab_ + (first_ ? vH0[i] : vH1[i])), Ad_ + i * 1024); \
-        });                                                                                        \
+        /* (a uniform branch instead of a per-lane select of the offset in front of every DMA) */   \
+        if (first_) {                                                                              \
+            static_for<ARH>([&](auto ic) {                                                         \
+                constexpr int i = decltype(ic)::value;                                             \
+                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH0[i], Ad_ + i * 1024);                 \
+            });                                                                                    \
+        } else {                                                                                   \
+            static_for<ARH>([&](auto ic) {                                                         \
+                constexpr int i = decltype(ic)::value;                                             \
+                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH1[i], Ad_ + i * 1024);                 \
+            });                                                                                    \
+        }                                                                                          \
         ++ga;                                                                                      \
     }
 
@@ -885,7 +918,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                 if (feed) {
                     static_for<BR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                        dma16s(wb, vB[i], Bd + i * 1024);
                     });
                 }
 #ifdef SR3_EXPERIMENTS
@@ -920,13 +953,20 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             const bool first2 = c0 < C2a;
             const char *ab = reinterpret_cast<const char *>(first2 ? p.in2.p + c0 : p.in2b.p + (c0 - C2a));
             const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
-            static_for<AR>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(ab + (first2 ? vA2[i] : vA2b[i])), Ad + i * 1024);
-            });
+            if (first2) {
+                static_for<AR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16s(ab, vA2[i], Ad + i * 1024);
+                });
+            } else {
+                static_for<AR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    dma16s(ab, vA2b[i], Ad + i * 1024);
+                });
+            }
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
+                dma16s(wb, vB2[i], Bd + i * 1024);
             });
             producer_sync<0>();
             ++k;
@@ -1316,11 +1356,18 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
         const char *ab_ = reinterpret_cast<const char *>((first_ ? p.in0.p : p.in1.p) + (first_ ? c0a_ : c0a_ - C0)) + \
                           (size_t)(DY) * Wp * Cs_ * 4;                                             \
         float *Ad_ = Aring + (ga & 1) * ASTG + w * 256;                                            \
-        static_for<ARH>([&](auto ic) {                                                             \
-            constexpr int i = decltype(ic)::value;                                                 \
-            if ((4 * i + w) * 8 < rows_a)                                                          \
-                dma16(reinterpret_cast<const float *>(ab_ + (first_ ? vH0[i] : vH1[i])), Ad_ + i * 1024); \
-        });                                                                                        \
+        /* (a uniform branch instead of a per-lane select of the offset in front of every DMA) */   \
+        if (first_) {                                                                              \
+            static_for<ARH>([&](auto ic) {                                                         \
+                constexpr int i = decltype(ic)::value;                                             \
+                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH0[i], Ad_ + i * 1024);                 \
+            });                                                                                    \
+        } else {                                                                                   \
+            static_for<ARH>([&](auto ic) {                                                         \
+                constexpr int i = decltype(ic)::value;                                             \
+                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH1[i], Ad_ + i * 1024);                 \
+            });                                                                                    \
+        }                                                                                          \
         ++ga;                                                                                      \
     }
         // first operands of a tile: halo group (chunk 0, dy 0) into A stage 0, B tile of K-step 0 into B stage 0
@@ -1331,7 +1378,7 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
             float *Bd = Bring + w * 256;
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                dma16s(wb, vB[i], Bd + i * 1024);
             });
         };
         int v = blockIdx.x;
@@ -1360,7 +1407,7 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
                         const char *wb = wbase + (size_t)tap * tapstride * 4;
                         static_for<BR>([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
-                            dma16(reinterpret_cast<const float *>(wb + vB[i]), Bd + i * 1024);
+                            dma16s(wb, vB[i], Bd + i * 1024);
                         });
                     }
                     producer_sync<0>();
@@ -1375,13 +1422,20 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
                 const bool first2 = c0 < C2a;
                 const char *ab = reinterpret_cast<const char *>(first2 ? p.in2.p + c0 : p.in2b.p + (c0 - C2a));
                 const char *wb = reinterpret_cast<const char *>(p.w2 + c0);
-                static_for<AR>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    dma16(reinterpret_cast<const float *>(ab + (first2 ? vA2[i] : vA2b[i])), Ad + i * 1024);
-                });
+                if (first2) {
+                    static_for<AR>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        dma16s(ab, vA2[i], Ad + i * 1024);
+                    });
+                } else {
+                    static_for<AR>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        dma16s(ab, vA2b[i], Ad + i * 1024);
+                    });
+                }
                 static_for<BR>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    dma16(reinterpret_cast<const float *>(wb + vB2[i]), Bd + i * 1024);
+                    dma16s(wb, vB2[i], Bd + i * 1024);
                 });
                 producer_sync<0>();
                 ++k;
