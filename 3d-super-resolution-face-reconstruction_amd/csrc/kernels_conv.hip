@@ -82,17 +82,25 @@ __device__ __forceinline__ void dma16(const float *g, float *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// The same with the address in the instruction's own (SGPR base) + (32-bit VGPR offset) form. Both halves are made
-// opaque to the optimiser at the point of use: left visible, base + zext(offset) is reassociated, tap-invariant
-// 64-bit sums are hoisted as VGPR pairs (18 pairs in the unrolled 3x3 loop) and every DMA pays a 64-bit vector
-// add; vector instructions of the producer waves compete with the consumers' MFMAs for issue (same box:
-// 17.45 -> 17.18 ms per B = 64 step for the weight tiles alone, profiles/README.md finding 48).
+// The same from a wave-uniform base + a per-lane 32-bit byte offset, with NO vector arithmetic in front of the DMA:
+// written as base + zext(offset) the optimiser reassociates the sum, hoists tap-invariant 64-bit parts into VGPR
+// pairs (18 pairs in the unrolled 3x3 loop) and pays a 64-bit vector add per DMA — vector instructions of the
+// producer waves compete with the consumers' MFMAs for issue (same box, B = 64 step: 17.45 -> 17.07 ms in f16x3,
+// 44.4 -> 40.8 ms in f32 mode; profiles/README.md finding 48).
+//  BUF: buffer_load ... lds — a resource descriptor over the base (scalar registers only), the offset goes into
+//       the instruction as it is. Best where the MFMAs are the critical path (the 128-row tiles).
+//  !BUF: plain global_load_lds on base + offset, addresses left to the optimiser. Best where the producers' own
+//       issue rate is the critical path (the 64x64 tile of the small batches): the descriptor set-up of the buffer
+//       form, or pinning global_load_lds to its (SGPR base) + (VGPR offset) form with opaque operands (one v_mov per
+//       DMA), cost config 1 (8 -> 16, B = 4) 2-3 %.
+template <bool BUF>
 __device__ __forceinline__ void dma16s(const char *sbase, unsigned voff, float *lds_wave_base) {
-#ifndef SR3_NO_OPAQUE_BASE
-    asm volatile("" : "+s"(sbase));
-    asm volatile("" : "+v"(voff));
-#endif
-    dma16(reinterpret_cast<const float *>(sbase + voff), lds_wave_base);
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(sbase), 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, (int)voff, 0, 0, 0);
+    } else {
+        dma16(reinterpret_cast<const float *>(sbase + voff), lds_wave_base);
+    }
 }
 
 // KS: 1 | 2 | 3 (the tap loop is unrolled); nearest x2 upsampling never reaches the kernel (launch_conv_up2)
@@ -383,6 +391,7 @@ template <int BM, int BN, int WGM, int WGN, int KS, int PREC, int NS>
 __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 160 * 1024 ? 6 : 4)) void conv_igemm_dma_f32(const ConvParams p_in) {
     const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
+    constexpr bool DMA_BUF = !(BM == 64 && BN == 64);   // (see dma16s)
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;     // DMA instructions per producer wave and K-step
@@ -499,18 +508,18 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
                     if (first) {
                         static_for<AR>([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
-                            dma16s(ab, vA0[i], Ad + i * 1024);
+                            dma16s<DMA_BUF>(ab, vA0[i], Ad + i * 1024);
                         });
                     } else {
                         static_for<AR>([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
-                            dma16s(ab, vA1[i], Ad + i * 1024);
+                            dma16s<DMA_BUF>(ab, vA1[i], Ad + i * 1024);
                         });
                     }
                     const char *wb = (SR3_DBG(p) & 2) ? reinterpret_cast<const char *>(p.w) : wbase + (size_t)tap * tapstride * 4;
                     static_for<BR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        dma16s(wb, vB[i], Bd + i * 1024);
+                        dma16s<DMA_BUF>(wb, vB[i], Bd + i * 1024);
                     });
                 }
                 if (k >= NS - 2) producer_sync<(NS - 2) * (AR + BR)>();
@@ -527,17 +536,17 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
             if (first2) {
                 static_for<AR>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    dma16s(ab, vA2[i], Ad + i * 1024);
+                    dma16s<DMA_BUF>(ab, vA2[i], Ad + i * 1024);
                 });
             } else {
                 static_for<AR>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    dma16s(ab, vA2b[i], Ad + i * 1024);
+                    dma16s<DMA_BUF>(ab, vA2b[i], Ad + i * 1024);
                 });
             }
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16s(wb, vB2[i], Bd + i * 1024);
+                dma16s<DMA_BUF>(wb, vB2[i], Bd + i * 1024);
             });
             if (k >= NS - 2) producer_sync<(NS - 2) * (AR + BR)>();
             ++k;
@@ -887,12 +896,12 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         if (first_) {                                                                              \
             static_for<ARH>([&](auto ic) {                                                         \
                 constexpr int i = decltype(ic)::value;                                             \
-                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH0[i], Ad_ + i * 1024);                 \
+                if ((4 * i + w) * 8 < rows_a) dma16s<true>(ab_, vH0[i], Ad_ + i * 1024);                 \
             });                                                                                    \
         } else {                                                                                   \
             static_for<ARH>([&](auto ic) {                                                         \
                 constexpr int i = decltype(ic)::value;                                             \
-                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH1[i], Ad_ + i * 1024);                 \
+                if ((4 * i + w) * 8 < rows_a) dma16s<true>(ab_, vH1[i], Ad_ + i * 1024);                 \
             });                                                                                    \
         }                                                                                          \
         ++ga;                                                                                      \
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                 if (feed) {
                     static_for<BR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        dma16s(wb, vB[i], Bd + i * 1024);
+                        dma16s<true>(wb, vB[i], Bd + i * 1024);
                     });
                 }
 #ifdef SR3_EXPERIMENTS
@@ -956,17 +965,17 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             if (first2) {
                 static_for<AR>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    dma16s(ab, vA2[i], Ad + i * 1024);
+                    dma16s<true>(ab, vA2[i], Ad + i * 1024);
                 });
             } else {
                 static_for<AR>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    dma16s(ab, vA2b[i], Ad + i * 1024);
+                    dma16s<true>(ab, vA2b[i], Ad + i * 1024);
                 });
             }
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16s(wb, vB2[i], Bd + i * 1024);
+                dma16s<true>(wb, vB2[i], Bd + i * 1024);
             });
             producer_sync<0>();
             ++k;
@@ -1360,12 +1369,12 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
         if (first_) {                                                                              \
             static_for<ARH>([&](auto ic) {                                                         \
                 constexpr int i = decltype(ic)::value;                                             \
-                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH0[i], Ad_ + i * 1024);                 \
+                if ((4 * i + w) * 8 < rows_a) dma16s<true>(ab_, vH0[i], Ad_ + i * 1024);                 \
             });                                                                                    \
         } else {                                                                                   \
             static_for<ARH>([&](auto ic) {                                                         \
                 constexpr int i = decltype(ic)::value;                                             \
-                if ((4 * i + w) * 8 < rows_a) dma16s(ab_, vH1[i], Ad_ + i * 1024);                 \
+                if ((4 * i + w) * 8 < rows_a) dma16s<true>(ab_, vH1[i], Ad_ + i * 1024);                 \
             });                                                                                    \
         }                                                                                          \
         ++ga;                                                                                      \
@@ -1378,7 +1387,7 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
             float *Bd = Bring + w * 256;
             static_for<BR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                dma16s(wb, vB[i], Bd + i * 1024);
+                dma16s<true>(wb, vB[i], Bd + i * 1024);
             });
         };
         int v = blockIdx.x;
@@ -1407,7 +1416,7 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
                         const char *wb = wbase + (size_t)tap * tapstride * 4;
                         static_for<BR>([&](auto ic) {
                             constexpr int i = decltype(ic)::value;
-                            dma16s(wb, vB[i], Bd + i * 1024);
+                            dma16s<true>(wb, vB[i], Bd + i * 1024);
                         });
                     }
                     producer_sync<0>();
@@ -1425,17 +1434,17 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
                 if (first2) {
                     static_for<AR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        dma16s(ab, vA2[i], Ad + i * 1024);
+                        dma16s<true>(ab, vA2[i], Ad + i * 1024);
                     });
                 } else {
                     static_for<AR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
-                        dma16s(ab, vA2b[i], Ad + i * 1024);
+                        dma16s<true>(ab, vA2b[i], Ad + i * 1024);
                     });
                 }
                 static_for<BR>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    dma16s(wb, vB2[i], Bd + i * 1024);
+                    dma16s<true>(wb, vB2[i], Bd + i * 1024);
                 });
                 producer_sync<0>();
                 ++k;
