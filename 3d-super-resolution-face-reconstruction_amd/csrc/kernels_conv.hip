@@ -1078,7 +1078,69 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
 #else
         constexpr bool x_rd = true, x_bar = true, x_mma = true;
 #endif
-        for (int kt = 0; kt < nk; ++kt) {
+        int kt = 0;
+#if SR3_CONV_VARIANT >= 1
+        if constexpr (ONESEG) {
+            // Halo-phase K loop WITHOUT address arithmetic. The fragment addresses of K-step kt = KS g + dx depend on kt
+            // through (B stage kt & 1, A stage g & 1, row shift dx) only: a pattern of period 2 KS. The loop is unrolled
+            // over one period, so every read is one of 2 KS + 2 lane-constant base registers (row shift dx enters the
+            // swizzle term, hence one A base pair per dx) plus an immediate for stage / row tile / column tile. Vector
+            // instructions compete with the MFMAs for issue; this removes 12 of the consumers' 14 per K-step. The last
+            // K-steps (the last 3 or 6 of the halo phase, the fused 1x1 K-steps) run through the general loop below.
+            constexpr int PER = 2 * KS;
+            // LDS byte addresses (the dynamic LDS segment starts at 0 and every row is 128-byte aligned, so the lo
+            // chunk of a row — chunk index ^ 4 — is the hi address ^ 64: one base register per dx and one for B)
+            typedef const h16x8 __attribute__((address_space(3))) *lds_frag;
+            auto lds_addr = [](const float *pp) { return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)pp; };
+            unsigned avh[KS];
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+                const int R_ = rhalo[0] + dx, sw_ = (R_ >> 1) & 7;
+                avh[dx] = lds_addr(Aring + R_ * ROWF + ((q ^ sw_) & 7) * 4);
+            }
+            const unsigned bvh = lds_addr(Bbase + bho);
+            // one K-step of the pattern at position u of the period (the fragments behind it follow the pattern too)
+            auto kstep = [&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int BS = u & 1, UN = (u + 1) % PER, BSN = (u + 1) & 1, ASN = (UN / KS) & 1, DXN = UN % KS;
+                // (80-register kernel: the lo addresses are recomputed where they are used — one v_xor — instead
+                // of being hoisted out of the loop as four more live registers, which spilled fragments)
+                auto lo_of = [](unsigned hi) {
+                    unsigned lo;
+                    if constexpr (BN == 64) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(lo) : "v"(hi));
+                    else lo = hi ^ 64u;
+                    return lo;
+                };
+                const unsigned bvl = lo_of(bvh);
+#pragma unroll
+                for (int nt = 0; nt < NT - 1; ++nt) {
+                    bqh[(nt + 1) & 1] = *(lds_frag)(bvh + (BS * BSTG + (nt + 1) * 16 * ROWF) * 4);
+                    bql[(nt + 1) & 1] = *(lds_frag)(bvl + (BS * BSTG + (nt + 1) * 16 * ROWF) * 4);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) SR3_MMA16(mt, nt, nt & 1)
+                }
+                __syncthreads();
+                bqh[0] = *(lds_frag)(bvh + BSN * BSTG * 4);
+                bql[0] = *(lds_frag)(bvl + BSN * BSTG * 4);
+                const unsigned avl_ = lo_of(avh[DXN]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    SR3_MMA16(mt, NT - 1, (NT - 1) & 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                    ah[mt] = *(lds_frag)(avh[DXN] + (ASN * ASTG + mt * 16 * ROWF) * 4);
+                    al[mt] = *(lds_frag)(avl_ + (ASN * ASTG + mt * 16 * ROWF) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // (strictly less: the K-step behind a pass must still be one of the pattern. Peeling the last period so that
+            // it runs here too — only its last K-step fetching through the general path — measured 0.5 % SLOWER over the
+            // step than leaving the last 3 or 6 halo K-steps to the general loop, which measured 0.5 % faster than no
+            // pattern loop at all; same box, three alternating pairs each.)
+            for (; kt + PER < nkh; kt += PER) static_for<PER>([&](auto uc) { kstep(uc); });
+        }
+#endif
+        for (; kt < nk; ++kt) {
             const int kn = min(kt + 1, nk - 1);     // after the last K-step: re-read, unused
 #if SR3_CONV_VARIANT >= 1
             // the next K-step's A addresses are computed in the shadow of the first columns' MFMAs and
