@@ -786,7 +786,10 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     constexpr int ASTG = RA * ROWF, BSTG = BN * ROWF;
     static_assert((RA % 8) == 0, "A stage rows");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // (128-byte alignment: the pattern K loop derives a row's lo-chunk address as hi ^ 64; every ring row is 128 bytes and
+    // both rings start at multiples of 128 bytes)
+    extern __shared__ __attribute__((aligned(128))) float smem[];
+    static_assert((ASTG * 4) % 128 == 0 && (BSTG * 4) % 128 == 0, "ring stages are whole 128-byte rows");
     float *Aring = smem;                    // [2][RA][32]
     float *Bring = smem + 2 * ASTG;         // [2][BN][32]
     int *rowpix = reinterpret_cast<int *>(smem + 2 * ASTG + 2 * BSTG);
