@@ -910,6 +910,8 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         ++ga;                                                                                      \
     }
 
+        int nh = 0;                                     // halo DMA instructions of this wave per group
+        static_for<ARH>([&](auto ic) { if ((4 * decltype(ic)::value + w) * 8 < rows_a) ++nh; });
         int k = 0;
         SR3_ISSUE_HALO(0, 0)
         for (int c0 = 0; c0 < Cin; c0 += BK) {
@@ -918,13 +920,9 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                 constexpr int tap = decltype(tc)::value;
                 constexpr int dy = tap / KS, dx = tap % KS;
                 const bool feed = !(SR3_DBG(p) & 1) || k == 0;      // experiment: operands only for the first K-step
-                if (dx == 1 && feed) {  // the stage of group g-1 is free once K-step KS*g - 1 has been read
-                    if (dy < KS - 1) {
-                        SR3_ISSUE_HALO(c0, dy + 1)
-                    } else if (c0 + BK < Cin) {
-                        SR3_ISSUE_HALO(c0 + BK, 0)
-                    }
-                }
+                // The B tile of this K-step goes out FIRST: the consumers wait for it at the very next barrier. The A
+                // halo group issued at dx == 1 is not read before the K-step after next, so it goes out behind the B
+                // tile and stays in flight across this K-step's barrier (counted wait: the wave's nh youngest DMAs).
                 float *Bd = Bring + (k & 1) * BSTG + w * 256;
                 const char *wb = wbase + (size_t)tap * tapstride * 4;
                 if (feed) {
@@ -932,6 +930,16 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                         constexpr int i = decltype(ic)::value;
                         dma16s<true>(wb, vB[i], Bd + i * 1024);
                     });
+                }
+                bool halo_now = false;
+                if (dx == 1 && feed) {  // the stage of group g-1 is free once K-step KS*g - 1 has been read
+                    if (dy < KS - 1) {
+                        SR3_ISSUE_HALO(c0, dy + 1)
+                        halo_now = true;
+                    } else if (c0 + BK < Cin) {
+                        SR3_ISSUE_HALO(c0 + BK, 0)
+                        halo_now = true;
+                    }
                 }
 #ifdef SR3_EXPERIMENTS
                 {   // experiment (profiles/README.md, GroupNorm-apply fusion): bits 8..15 = N dummy vector operations per
@@ -953,7 +961,15 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                     if (zs == 1234.5f) rowimg[0] = 1;     // keep the chains alive
                 }
 #endif
-                if (!(SR3_DBG(p) & 8)) producer_sync<0>();          // experiment bit 3: no barriers (timing only)
+                if (!(SR3_DBG(p) & 8)) {                            // experiment bit 3: no barriers (timing only)
+                    if (dx == 1 && halo_now) {
+                        static_for<ARH + 1>([&](auto nc) {
+                            if (nh == decltype(nc)::value) producer_sync<decltype(nc)::value>();
+                        });
+                    } else {
+                        producer_sync<0>();
+                    }
+                }
                 ++k;
             });
         }
