@@ -309,3 +309,17 @@ def test_inplace_splitk_equals_two_kernel_form(tmp_path):
     err = np.abs(res["inplace"] - res["two_kernel"]).max()
     print(f"in-place vs two-kernel split-K, 3 steps: max abs diff {err:.2e}")
     assert err < 2e-6
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_small_batch_runs_are_bit_identical(big128, prec):
+    """Small batches run their split-K convs in place: whichever block arrives last at a tile adds the partials — in
+    split order, so repeated runs must agree bit for bit (B = 1 and B = 3 at 128x128, the six-attention variant)."""
+    e, cfg, sd = big128
+    e.set_precision(prec)
+    for B in (1, 3):
+        cond = synth.synth_cond(B, 128, 16, 11 + B)
+        first = _steps(e, cond, 3, 777)
+        assert np.isfinite(first).all() and first.std() > 0.3
+        for _ in range(3):
+            np.testing.assert_array_equal(_steps(e, cond, 3, 777), first)
