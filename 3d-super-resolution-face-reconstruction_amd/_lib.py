@@ -21,6 +21,10 @@ class Sr3Error(RuntimeError):
     pass
 
 
+class Sr3RangeWarning(RuntimeWarning):
+    """A call in split-f16 mode left the fp16 range and was finished in exact f32 (SR3_OK_F32_FALLBACK)."""
+
+
 class UnetCfg(C.Structure):
     _fields_ = [
         ("in_channel", C.c_int32),
@@ -49,6 +53,8 @@ PROTOTYPES = {
     "sr3_last_error": (C.c_char_p, []),
     "sr3_set_stream": (_I, [_P, _P]),
     "sr3_synchronize": (_I, [_P]),
+    "sr3_wait_for_stream": (_I, [_P, _P]),
+    "sr3_stream_wait_for_ctx": (_I, [_P, _P]),
     "sr3_set_precision": (_I, [_P, _I]),
     "sr3_num_params": (_I, [_P]),
     "sr3_param_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(_I)]),
@@ -62,6 +68,9 @@ PROTOTYPES = {
     "sr3_sample_step": (_I, [_P, _I, _F]),
     "sr3_sample_end": (_I, [_P, _F]),
     "sr3_range_check": (_I, [_P]),
+    "sr3_set_range_policy": (_I, [_P, _I]),
+    "sr3_fallback_calls": (_I, [_P]),
+    "sr3_last_warning": (C.c_char_p, []),
     "sr3_philox_normal": (_I, [_P, _U64, _U64, C.c_uint32, _I, _F]),
     "sr3_profile_enable": (_I, [_P, _I]),
     "sr3_profile_reset": (_I, [_P]),
@@ -108,7 +117,17 @@ def load() -> C.CDLL:
     return lib
 
 
+SR3_OK_F32_FALLBACK = 1
+
+
 def check(rc: int) -> None:
-    if rc != 0:
-        msg = load().sr3_last_error()
-        raise Sr3Error(msg.decode("utf-8", "replace") if msg else f"libsr3hip error {rc}")
+    """< 0: raise with the library's message; > 0 (SR3_OK_F32_FALLBACK): the result is valid, warn."""
+    if rc == 0:
+        return
+    if rc > 0:
+        import warnings
+        msg = load().sr3_last_warning()
+        warnings.warn(Sr3RangeWarning(msg.decode("utf-8", "replace") if msg else "f32 fallback"), stacklevel=3)
+        return
+    msg = load().sr3_last_error()
+    raise Sr3Error(msg.decode("utf-8", "replace") if msg else f"libsr3hip error {rc}")

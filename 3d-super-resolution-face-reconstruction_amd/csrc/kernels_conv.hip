@@ -681,7 +681,7 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
         // Visibility across the XCDs' L2s without a device-scope fence (a release fence writes the WHOLE L2 back:
         // measured +22 us per conv): the partials are stored and loaded as relaxed device-scope atomics — write-
         // through stores / loads that bypass the non-coherent cache levels (sc1) — and ordered against the counter
-        // by waiting for the stores' completion (s_waitcnt, i.e. a workgroup-scope release) before the barrier.
+        // by an explicit `s_waitcnt vmcnt(0)` in every consumer wave before the barrier (see below).
         // Addresses: wave-uniform 64-bit base + one 32-bit lane offset (the partial buffer is far below 4 GiB).
         const size_t MC = (size_t)M * Cout;
         const unsigned lane_off = ((unsigned)(4 * lh) * (unsigned)Cout + (unsigned)li) * 4u;
@@ -697,7 +697,13 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     __hip_atomic_store(elem(split, mi, ni, r), acc[mi][ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // the stores have completed ...
+        // The guarantee relied on: an sc1 (agent-scope, write-through) store is counted by vmcnt until the coherence
+        // point (the memory side past the XCD's L2) has acknowledged it, so `s_waitcnt vmcnt(0)` in EVERY consumer wave,
+        // then the barrier, then the counter RMW orders "partials visible device-wide" before "block counted". A
+        // workgroup-scope release fence alone does NOT emit that wait (without tgsplit it needs none; the round-2 code
+        // compiled to lgkmcnt(0) only), hence the explicit instruction.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the stores have completed ...
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();                            // ... in all four consumer waves, before the tile counts this block
         int *last_flag = reinterpret_cast<int *>(smem) + NS * STAGE - 4;   // (far behind the statistics staging area)
         if (threadIdx.x == 0) {
@@ -1820,13 +1826,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
                 const float4 b = *reinterpret_cast<const float4 *>(pm + (size_t)sp * sstride);
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
-            const int rem = m - img * HWo, oy = rem / p.Wout;
-            const size_t o = p.out.pix(img, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox) * Cout + n;
+            // (per pixel: a block of TP pixels straddles two images when HWo % TP != 0 — 14x14, 20x20 ... levels)
+            const int im = m / HWo;
+            const int rem = m - im * HWo, oy = rem / p.Wout;
+            const size_t o = p.out.pix(im, oy * p.out_step + p.out_oy, (rem - oy * p.Wout) * p.out_step + p.out_ox) * Cout + n;
             float v[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (p.bias) v[j] += p.bias[n + j];
-                if (p.chan_bias) v[j] += p.chan_bias[(size_t)img * p.chan_bias_stride + n + j];
+                if (p.chan_bias) v[j] += p.chan_bias[(size_t)im * p.chan_bias_stride + n + j];
                 if (p.resid.p) v[j] += p.resid_split ? load_split(p.resid.p, (unsigned)(o + j)) : p.resid.p[o + j];
                 if (p.out_f32) p.out.p[o + j] = v[j];
                 if (p.out_split.p != nullptr) {

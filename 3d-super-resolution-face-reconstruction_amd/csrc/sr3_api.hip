@@ -21,6 +21,7 @@ using namespace sr3;
 namespace {
 
 thread_local std::string g_err;
+thread_local std::string g_warn;
 
 int fail(const char *fmt, ...) {
     char buf[1024];
@@ -107,6 +108,7 @@ struct sr3_ctx {
     sr3_unet_cfg cfg;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t order_ev = nullptr;      // sr3_wait_for_stream / sr3_stream_wait_for_ctx
     std::vector<Param> params;
     std::vector<Module> mods;   // downs ‖ mid ‖ ups
     int n_downs = 0, n_mid = 0;
@@ -130,6 +132,13 @@ struct sr3_ctx {
     // split-f16 range check: kernels set *d_ovf when a value stored in the split format exceeds the
     // fp16 range (|v| > 65504); sr3_unet_forward / sr3_sample_end / sr3_range_check read it and fail
     int *d_ovf = nullptr, *h_ovf = nullptr;
+    // Range policy of the split-f16 mode (sr3_set_range_policy). strict: a call whose activations leave the fp16
+    // range FAILS (round-2 behaviour). Default (not strict): the call is FINISHED in the exact-f32 arithmetic —
+    // the reference computes in fp32 and has no such limit (unet.py:235-265) — and returns SR3_OK_F32_FALLBACK.
+    bool strict_range = false;
+    int fallback_calls = 0;             // calls finished by the f32 fallback since sr3_create
+    float *ckpt = nullptr;              // sr3_sample: NCHW copy of the sampler state at the last clean checkpoint
+    size_t ckpt_floats = 0;
     unsigned *tile_cnt = nullptr;       // ConvParams::tile_cnt: arrival counters of the in-place split-K convs (zero between launches)
 
     // workspace for one (B, H, W)
@@ -928,11 +937,29 @@ int range_reset(sr3_ctx *c) {
 // Synchronises the stream and fails if any kernel since the last reset stored a value beyond the
 // fp16 range in the split-f16 format (such a value would otherwise corrupt the residual stream
 // silently). The flag is cleared either way.
-int range_check(sr3_ctx *c, const char *what) {
+// synchronises, reads and clears the flag: 0 in range, 1 overflow, -1 HIP error
+int range_read(sr3_ctx *c) {
     HIP_OK(hipMemcpyAsync(c->h_ovf, c->d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     if (*c->h_ovf == 0) return 0;
     HIP_OK(hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream));
+    return 1;
+}
+
+int warn_fallback(sr3_ctx *c, const char *what, const char *redo) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: an activation exceeded the fp16 range (|v| > 65504) of the split-f16 format; %s was "
+             "recomputed in the exact f32 arithmetic (the reference computes in fp32 and has no such limit). "
+             "sr3_set_range_policy(ctx, 1) makes this an error instead; sr3_set_precision(ctx, 0) avoids the retry.",
+             what, redo);
+    g_warn = buf;
+    ++c->fallback_calls;
+    return SR3_OK_F32_FALLBACK;
+}
+
+int range_check(sr3_ctx *c, const char *what) {
+    const int r = range_read(c);
+    if (r <= 0) return r;
     return fail("%s: an activation exceeded the fp16 range (|v| > 65504) of the split-f16 format; the result is "
                 "invalid — run this model with the exact f32 arithmetic (sr3_set_precision(ctx, 0))", what);
 }
@@ -1080,12 +1107,14 @@ void sr3_destroy(sr3_ctx *c) {
     if (c->d_nl) (void)hipFree(c->d_nl);
     drop_graphs(c);
     if (c->d_ovf) (void)hipFree(c->d_ovf);
+    if (c->ckpt) (void)hipFree(c->ckpt);
     if (c->tile_cnt) (void)hipFree(c->tile_cnt);
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     if (c->d_step) (void)hipFree(c->d_step);
     for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1095,6 +1124,26 @@ int sr3_set_stream(sr3_ctx *c, void *hip_stream) {
     c->pflush();
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
     return 0;
+}
+
+// Stream ordering without host synchronisation (hosts that keep their own streams, e.g. torch): an event is
+// recorded on one stream and the other stream waits for it on the device.
+static int order_streams(sr3_ctx *c, hipStream_t first, hipStream_t then) {
+    if (first == then) return 0;
+    if (!c->order_ev) HIP_OK(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(c->order_ev, first));
+    HIP_OK(hipStreamWaitEvent(then, c->order_ev, 0));
+    return 0;
+}
+int sr3_wait_for_stream(sr3_ctx *c, void *other_stream) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    return order_streams(c, reinterpret_cast<hipStream_t>(other_stream), c->stream);
+}
+int sr3_stream_wait_for_ctx(sr3_ctx *c, void *other_stream) {
+    if (!c) return fail("null context");
+    HIP_OK(hipSetDevice(c->device));
+    return order_streams(c, c->stream, reinterpret_cast<hipStream_t>(other_stream));
 }
 
 int sr3_set_precision(sr3_ctx *c, int prec) {
@@ -1188,12 +1237,8 @@ int sr3_weights_missing(sr3_ctx *c) {
 
 int sr3_chan_bias_total(sr3_ctx *c) { return c ? c->nf_total : fail("null context"); }
 
-int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_dev, int B, int H, int W,
-                     float *out_dev) {
-    if (check_ready(c)) return -1;
-    if (!x_dev || !noise_level_dev || !out_dev) return fail("sr3_unet_forward: null pointer");
-    if (ensure_workspace(c, B, H, W)) return -1;
-    c->sampling = false;
+static int unet_forward_once(sr3_ctx *c, const float *x_dev, const float *noise_level_dev, int B, int H, int W,
+                             float *out_dev) {
     if (range_reset(c)) return -1;
     c->pbegin(F_MISC);
     launch_nchw_to_nhwc(x_dev, B, c->cfg.in_channel, c->x0, 0, c->stream);
@@ -1205,7 +1250,26 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     launch_nhwc_to_nchw(c->eps, 0, B, c->cfg.out_channel, out_dev, c->stream);
     c->pend();
     HIP_OK(hipGetLastError());
-    return c->prec ? range_check(c, "sr3_unet_forward") : 0;
+    return 0;
+}
+
+int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_dev, int B, int H, int W,
+                     float *out_dev) {
+    if (check_ready(c)) return -1;
+    if (!x_dev || !noise_level_dev || !out_dev) return fail("sr3_unet_forward: null pointer");
+    if (ensure_workspace(c, B, H, W)) return -1;
+    c->sampling = false;
+    if (unet_forward_once(c, x_dev, noise_level_dev, B, H, W, out_dev)) return -1;
+    if (!c->prec) return 0;
+    if (c->strict_range) return range_check(c, "sr3_unet_forward");
+    const int r = range_read(c);
+    if (r <= 0) return r;
+    // out of range: the caller still owns x and noise_level, so the forward is simply evaluated again in f32
+    c->prec = 0;
+    const int rc = unet_forward_once(c, x_dev, noise_level_dev, B, H, W, out_dev);
+    c->prec = 1;
+    if (rc) return -1;
+    return warn_fallback(c, "sr3_unet_forward", "the forward pass");
 }
 
 int sr3_set_schedule(sr3_ctx *c, int T, const float *noise_level, const float *recip, const float *recipm1,
@@ -1289,16 +1353,84 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
     if (!out_dev) return fail("sr3_sample: out_dev is null");
     if (sr3_sample_begin(c, cond_dev, B, H, W, noise_dev, seed, image_offset)) return -1;
     const int T = c->T, si = 1 | (T / 10);
-    const size_t slab = (size_t)B * c->cfg.out_channel * H * W;
+    const int C = c->cfg.out_channel, nc = c->cfg.in_channel - C;
+    const size_t slab = (size_t)B * C * H * W;
+    // Range guard of the split-f16 mode (default policy): the loop is cut into segments of `seg` steps. At every
+    // segment boundary the range flag is read (one stream synchronisation per segment: ~10 per call); while it is
+    // clean the sampler state is saved (NCHW copy, 12 B per pixel). When it trips, the state of the last clean
+    // boundary is restored and the REST of the loop runs in the exact-f32 arithmetic — every draw of the noise
+    // (injected slab or Philox draw index) and every frame slot is a function of t, so the replay is exact.
+    const bool guard = c->prec == 1 && !c->strict_range;
+    const int seg = std::max(1, T / 10);
+    if (guard && c->ckpt_floats < slab) {
+        if (c->ckpt) HIP_OK(hipFree(c->ckpt));
+        c->ckpt = nullptr; c->ckpt_floats = 0;
+        HIP_OK(hipMalloc(&c->ckpt, slab * sizeof(float)));
+        c->ckpt_floats = slab;
+    }
+    auto save = [&]() { launch_nhwc_to_nchw(c->x0, nc, B, C, c->ckpt, c->stream); };
+    int t_ck = T - 1, f_ck = 0;          // the checkpoint holds the state BEFORE step t_ck; f_ck frames were written by then
+    bool fell_back = false;
+    int rc = 0;
+    if (guard) {
+        const int r = range_read(c);     // (the initial state / its packed copy)
+        if (r < 0) return -1;
+        if (r > 0) { c->prec = 0; fell_back = true; }
+        else save();
+    }
     int f = 0;
     for (int t = T - 1; t >= 0; --t) {
+        if (guard && !fell_back && t != T - 1 && ((T - 1 - t) % seg) == 0) {
+            const int r = range_read(c);
+            if (r < 0) { rc = -1; break; }
+            if (r > 0) {
+                launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
+                if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
+                c->prec = 0; fell_back = true;
+                t = t_ck; f = f_ck;
+            } else {
+                save();
+                t_ck = t; f_ck = f;
+            }
+        }
         const float *nz = (noise_dev && t > 0) ? noise_dev + (size_t)(T - t) * slab : nullptr;
         float *fr = (frames_dev && (t % si == 0)) ? frames_dev + (size_t)(f++) * slab : nullptr;
-        if (step_impl(c, t, nz, fr)) return -1;
+        if (step_impl(c, t, nz, fr)) { rc = -1; break; }
         if (c->prof && (t % 8) == 0) c->pflush();  // bound the number of live events
+        if (guard && !fell_back && t == 0) {        // the last segment
+            const int r = range_read(c);
+            if (r < 0) { rc = -1; break; }
+            if (r > 0) {
+                launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
+                if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
+                c->prec = 0; fell_back = true;
+                t = t_ck + 1; f = f_ck;             // (the loop's --t resumes at t_ck)
+            }
+        }
     }
-    return sr3_sample_end(c, out_dev);
+    if (rc == 0) {
+        if (guard) {
+            c->pbegin(F_MISC);
+            launch_nhwc_to_nchw(c->x0, nc, c->wB, C, out_dev, c->stream);
+            c->pend();
+            if (hipGetLastError() != hipSuccess) rc = fail("sr3_sample: launch failed");
+            if (fell_back && rc == 0 && hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream) != hipSuccess) rc = fail("hipMemsetAsync failed");
+        } else {
+            rc = sr3_sample_end(c, out_dev);
+        }
+    }
+    if (fell_back) c->prec = 1;
+    if (rc) return rc;
+    return fell_back ? warn_fallback(c, "sr3_sample", "the rest of the loop from the last in-range checkpoint") : 0;
 }
+
+int sr3_set_range_policy(sr3_ctx *c, int strict) {
+    if (!c) return fail("null context");
+    c->strict_range = strict != 0;
+    return 0;
+}
+int sr3_fallback_calls(sr3_ctx *c) { return c ? c->fallback_calls : fail("null context"); }
+const char *sr3_last_warning(void) { return g_warn.c_str(); }
 
 int sr3_philox_normal(sr3_ctx *c, uint64_t seed, uint64_t image, uint32_t draw, int n, float *out_dev) {
     if (!c || !out_dev) return fail("sr3_philox_normal: null argument");

@@ -107,6 +107,7 @@ class GaussianDiffusion(nn.Module):
             nptr = noise.data_ptr()
         if seed is None:
             seed = self._draw_seed()
+        self.denoise_fn.ready()
         eng.sample(cond_ptr, B, H, W, out.data_ptr(), nptr, seed, image_offset,
                    frames.data_ptr() if frames is not None else None)
         self.denoise_fn.finish()
@@ -132,6 +133,7 @@ class GaussianDiffusion(nn.Module):
             # (init_state_kernel); regenerate it from the same (seed, image index) keys
             first = torch.empty_like(out)
             eng, n = self._engine(), out[0].numel()
+            self.denoise_fn.ready()
             for i in range(out.shape[0]):
                 eng.philox_normal_into(seed, i, 0, n, first[i].data_ptr())
             self.denoise_fn.finish()
@@ -160,13 +162,33 @@ class GaussianDiffusion(nn.Module):
         x = x.to(torch.float32).contiguous()
         B, _, H, W = x.shape
         cond = condition_x.to(torch.float32).contiguous() if condition_x is not None else None
-        eng.sample_begin(cond.data_ptr() if cond is not None else None, B, H, W, x.data_ptr(), 0, 0)
         if noise is None and t > 0:
             noise = torch.randn_like(x)
         nz = noise.to(torch.float32).contiguous() if (noise is not None and t > 0) else None
-        eng.sample_step(int(t), nz.data_ptr() if nz is not None else None)
         out = torch.empty_like(x)
-        eng.sample_end(out.data_ptr())
+
+        def one_step():
+            self.denoise_fn.ready()
+            eng.sample_begin(cond.data_ptr() if cond is not None else None, B, H, W, x.data_ptr(), 0, 0)
+            eng.sample_step(int(t), nz.data_ptr() if nz is not None else None)
+            eng.sample_end(out.data_ptr())
+
+        try:
+            one_step()
+        except Sr3Error as e:
+            # the step API cannot replay inside the library (the caller owns the noise); this facade still holds
+            # x, cond and noise, so an out-of-range split-f16 step is evaluated again in exact f32 — the
+            # reference computes in fp32 and has no range limit (unet.py:235-265)
+            if "fp16 range" not in str(e) or getattr(eng, "precision", "f32") != "f16x3" or self.denoise_fn.strict_range:
+                raise
+            import warnings
+            from ._lib import Sr3RangeWarning
+            eng.set_precision("f32")
+            try:
+                one_step()
+            finally:
+                eng.set_precision("f16x3")
+            warnings.warn(Sr3RangeWarning(f"p_sample(t={int(t)}) recomputed in exact f32: {e}"), stacklevel=2)
         self.denoise_fn.finish()
         return out
 

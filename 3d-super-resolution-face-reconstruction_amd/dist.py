@@ -20,10 +20,17 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def force_collective() -> bool:
+    """SR3_FORCE_COLLECTIVE=1: take the collective path even with ONE rank (the RCCL all-gather then runs as a
+    world-size-1 collective). Exists so that a single-GPU box exercises librccl initialisation and the product's
+    collective call before the first multi-GPU run."""
+    return os.environ.get("SR3_FORCE_COLLECTIVE", "0") not in ("", "0")
+
+
 def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     """Initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* (torch.distributed.run)."""
     rank, world, local = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collective()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {}
@@ -44,7 +51,7 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
 def all_gather_images(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """Gathers the per-rank [b_r, ...] slices (contiguous, shard_bounds order) into [n_total, ...]
     on every rank with a single collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective()):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     counts = [shard_bounds(n_total, world, r) for r in range(world)]

@@ -106,8 +106,24 @@ class Engine:
         _lib.check(self.lib.sr3_set_precision(self.ctx, self.PRECISIONS[name]))
         self.precision = name
 
+    def set_range_policy(self, strict: bool):
+        """split-f16 mode, activation beyond the fp16 range: strict=True fails the call; False (default)
+        finishes it in exact f32 and warns (`Sr3RangeWarning`)."""
+        _lib.check(self.lib.sr3_set_range_policy(self.ctx, 1 if strict else 0))
+
+    def fallback_calls(self) -> int:
+        return int(self.lib.sr3_fallback_calls(self.ctx))
+
     def synchronize(self):
         _lib.check(self.lib.sr3_synchronize(self.ctx))
+
+    def wait_for_stream(self, stream_handle: Optional[int]):
+        """The library's stream waits (on the device) for the work enqueued so far on `stream_handle`."""
+        _lib.check(self.lib.sr3_wait_for_stream(self.ctx, stream_handle or None))
+
+    def stream_wait_for_engine(self, stream_handle: Optional[int]):
+        """`stream_handle` waits (on the device) for the library work enqueued so far."""
+        _lib.check(self.lib.sr3_stream_wait_for_ctx(self.ctx, stream_handle or None))
 
     def device_bytes(self) -> int:
         return int(self.lib.sr3_device_bytes(self.ctx))

@@ -15,8 +15,8 @@ from typing import Dict
 import torch
 
 
-def _engine(netG_or_unet):
-    return getattr(netG_or_unet, "denoise_fn", netG_or_unet).engine()
+def _unet(netG_or_unet):
+    return getattr(netG_or_unet, "denoise_fn", netG_or_unet)
 
 
 def _check(sr: torch.Tensor) -> torch.Tensor:
@@ -33,7 +33,11 @@ def tensor2img(netG_or_unet, sr: torch.Tensor) -> torch.Tensor:
     sr = _check(sr)
     B, _, H, W = sr.shape
     out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=sr.device)
-    _engine(netG_or_unet).postprocess_u8(sr.data_ptr(), B, H, W, 0, 0, out.data_ptr(), None, None, None)
+    unet = _unet(netG_or_unet)
+    eng = unet.engine()
+    unet.ready()
+    eng.postprocess_u8(sr.data_ptr(), B, H, W, 0, 0, out.data_ptr(), None, None, None)
+    unet.finish()
     return out
 
 
@@ -48,8 +52,11 @@ def mica_inputs(netG_or_unet, sr: torch.Tensor, up: int = 224, blob: int = 112) 
     upi = torch.empty((B, up, up, 3), dtype=torch.uint8, device=dev)
     images = torch.empty((B, 3, up, up), dtype=torch.float32, device=dev)
     arc = torch.empty((B, 3, blob, blob), dtype=torch.float32, device=dev)
-    _engine(netG_or_unet).postprocess_u8(sr.data_ptr(), B, H, W, up, blob, img.data_ptr(), upi.data_ptr(),
-                                         images.data_ptr(), arc.data_ptr())
+    unet = _unet(netG_or_unet)
+    eng = unet.engine()
+    unet.ready()
+    eng.postprocess_u8(sr.data_ptr(), B, H, W, up, blob, img.data_ptr(), upi.data_ptr(), images.data_ptr(), arc.data_ptr())
+    unet.finish()
     return {"sr_img": img, "sr_up_img": upi, "images": images, "arcface": arc}
 
 
@@ -59,5 +66,9 @@ def create_tensor_blob(netG_or_unet, sr: torch.Tensor, blob: int = 112) -> torch
     sr = _check(sr)
     B, _, H, W = sr.shape
     out = torch.empty((B, 3, blob, blob), dtype=torch.float32, device=sr.device)
-    _engine(netG_or_unet).postprocess_tensor_blob(sr.data_ptr(), B, H, W, blob, out.data_ptr())
+    unet = _unet(netG_or_unet)
+    eng = unet.engine()
+    unet.ready()
+    eng.postprocess_tensor_blob(sr.data_ptr(), B, H, W, blob, out.data_ptr())
+    unet.finish()
     return out

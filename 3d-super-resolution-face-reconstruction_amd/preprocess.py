@@ -18,5 +18,7 @@ def bicubic_sr(netG_or_unet, lr_u8: torch.Tensor, r: int, return_u8: bool = Fals
     B, H, W, _ = x.shape
     out = torch.empty((B, 3, r, r), dtype=torch.float32, device=x.device)
     u8 = torch.empty((B, r, r, 3), dtype=torch.uint8, device=x.device) if return_u8 else None
+    unet.ready()
     eng.preprocess_bicubic(x.data_ptr(), B, H, W, r, r, out.data_ptr(), u8.data_ptr() if return_u8 else None)
+    unet.finish()
     return (out, u8) if return_u8 else out

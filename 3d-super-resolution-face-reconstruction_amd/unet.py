@@ -87,6 +87,9 @@ class UNet(nn.Module):
         # accuracy, ~3x faster; default) or "f32" = exact fp32 MFMA. Both pass the 1e-3 parity bar
         # against the reference with ~1e-6 (tests/test_gpu_sampler.py).
         self.precision = os.environ.get("SR3_PRECISION", "f16x3")
+        # split-f16 range policy: False (default) = a call whose activations leave the fp16 range is finished in
+        # exact f32 with an `Sr3RangeWarning`; True = it raises `Sr3Error` (sr3_set_range_policy)
+        self.strict_range = bool(int(os.environ.get("SR3_STRICT_RANGE", "0")))
 
     # ---- engine management -------------------------------------------------------------------
     def _device_index(self) -> int:
@@ -109,18 +112,29 @@ class UNet(nn.Module):
         # Stream ordering, made explicit: on a non-default torch stream the library enqueues on that very
         # stream. On the default (null) stream it uses its own stream (hipGraph capture is not allowed
         # on the null stream), so pending torch work is waited for here and `finish()` waits for the
-        # library before torch (or a collective) touches the results.
+        # library before torch (or a collective) touches the results — both as device-side event waits
+        # (`ready()` / `finish()`), not host synchronisations.
         cur = torch.cuda.current_stream(idx)
         self._own_stream = cur.cuda_stream == 0
-        if self._own_stream:
-            cur.synchronize()
         self._engine.set_stream(cur.cuda_stream)
+        if getattr(self._engine, "_strict", None) != self.strict_range:
+            self._engine.set_range_policy(self.strict_range)
+            self._engine._strict = self.strict_range
         return self._engine
 
-    def finish(self) -> None:
-        """Call after enqueueing library work whose results torch will read (see engine())."""
+    def ready(self) -> None:
+        """Call right before enqueueing library work that reads tensors torch produced (after the last
+        `.to()` / `.contiguous()` of the inputs): the library's stream waits on the device for torch's stream —
+        an event, no host stall."""
         if self._engine is not None and getattr(self, "_own_stream", True):
-            self._engine.synchronize()
+            self._engine.wait_for_stream(0)
+
+    def finish(self) -> None:
+        """Call after enqueueing library work whose results torch will read (see engine()): torch's stream
+        waits on the device for the library's stream — results are ordered for every later torch operation
+        (including `.cpu()` and collectives enqueued from torch's current stream) without a host synchronisation."""
+        if self._engine is not None and getattr(self, "_own_stream", True):
+            self._engine.stream_wait_for_engine(0)
 
     def _sync_weights(self) -> None:
         for name, p in self.named_parameters():
@@ -141,6 +155,7 @@ class UNet(nn.Module):
         if nl.numel() != B:
             raise RuntimeError(f"noise level must have {B} entries, got {nl.numel()}")
         out = torch.empty((B, self.cfg.out_channel, H, W), dtype=torch.float32, device=x.device)
+        self.ready()
         eng.unet_forward(x.data_ptr(), nl.data_ptr(), B, H, W, out.data_ptr())
         self.finish()
         return out

@@ -23,8 +23,9 @@ The JSON line also carries
                16/36 of the MACs on the sub-pixel Upsample convs) over the same peak
   full_loop    ONE whole sr3_sample call (T steps, intermediate frames recorded) timed end to end:
                the sustained rate next to the K-step figure
-  cpu_baseline the numpy oracle (a port of the reference's CPU path) timed on this host on a
-               bounded sample, and the GPU-vs-oracle parity of that same sample.
+  cpu_baseline oracle/sr3_oracle_aten.py (the build's restatement on torch's CPU operators — what the
+               reference's CPU path runs on) timed on this host on a bounded sample ("port-aten"), and the
+               GPU-vs-oracle parity of that same sample.
 """
 import argparse
 import importlib
@@ -63,25 +64,37 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary measurement of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the timed whole-loop sr3_sample call (N=1 only)")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     return ap.parse_args()
 
 
 def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
-    """Oracle (CPU port) on a bounded sample of the same workload + parity of the GPU on it."""
+    """CPU baseline on a bounded sample of the same workload + parity of the GPU on that sample.
+
+    The timed code is oracle/sr3_oracle_aten.py: the build's own restatement of the reference's sampler on torch's
+    CPU operators (F.conv2d / F.group_norm / bmm) — the operator library the reference's CPU path itself runs on
+    (nn.Conv2d / nn.GroupNorm, unet.py:62,84,87) — pinned to the reference-made fixtures by
+    tests/test_oracle_golden.py. Never the reference's files (they do not exist on the GPU box)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import sr3_oracle as oracle      # checker / baseline only
+    import torch
+    import sr3_oracle_aten as aten      # checker / baseline only
     metrics = importlib.import_module(PKG + ".metrics")
     B, r, T, K = args.cpu_batch, args.res, args.T, args.cpu_steps
     cond = synth.synth_cond(B, r, args.lres, 4242)
     noise = synth.synth_noise(K + 1, B, 3, r, r, 4242)
-    sch = oracle.noise_schedule(sched_opt)
-    x = noise[0]
-    t0 = time.perf_counter()
-    for k in range(K):
-        x = oracle.p_sample(sd, cfg, sch, x, T - 1 - k, cond, noise[k + 1])
-    dt = time.perf_counter() - t0
+    sch = aten.noise_schedule(sched_opt)
+    tsd = aten.to_torch_state(sd)
+    threads = torch.get_num_threads()
+    tc = torch.from_numpy(cond)
+    x = torch.from_numpy(noise[0].copy())
+    with torch.no_grad():
+        aten.p_sample(tsd, cfg, sch, x, T - 1, tc, torch.from_numpy(noise[1].copy()))      # untimed warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        for k in range(K):
+            x = aten.p_sample(tsd, cfg, sch, x, T - 1 - k, tc, torch.from_numpy(noise[k + 1].copy()))
+        dt = time.perf_counter() - t0
+    x = x.numpy()
     # the same K steps on the GPU with the same injected noise
     dc, dn, out = eng.to_device(cond), eng.to_device(noise), eng.buffer(B * 3 * r * r)
     slab = B * 3 * r * r * 4
@@ -90,14 +103,14 @@ def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
         eng.sample_step(T - 1 - k, dn.ptr + (k + 1) * slab)
     eng.sample_end(out.ptr)
     got = out.download((B, 3, r, r))
-    try:
-        import threadpoolctl
-        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count()
     base = {
-        "value": B / (T * dt / K), "unit": "img/s", "cores": int(cores), "kind": "port",
-        "sample": f"{K} p_sample steps of B={B} at {r}x{r} with the numpy oracle ({dt:.1f} s), scaled to T={T}",
+        "value": B / (T * dt / K), "unit": "img/s", "cores": int(threads), "kind": "port-aten",
+        "host_cpus": os.cpu_count(),
+        "sample": (f"{K} p_sample steps of B={B} at {r}x{r} with oracle/sr3_oracle_aten.py (torch {torch.__version__} CPU "
+                   f"operators, {threads} intra-op threads, {dt:.1f} s after one warm-up step), scaled to T={T}"),
+        "provenance": ("the reference's own torch-CPU path measured by the survey in the build container (8 vCPU): "
+                       "0.25 s per image-step at 128x128 => ~0.004 img/s at T=1000 (BASELINE.md section 2); "
+                       "the reference itself cannot run on the GPU box"),
     }
     st = metrics.batch_psnr_stats(got, x)
     # psnr_db: mean over the images that differ after uint8 rounding (null if none differs — JSON has
@@ -174,7 +187,10 @@ def main():
     a, _ = distm.shard_bounds(B * world, world, rank)
     cond = torch.from_numpy(synth.synth_cond(B, r, args.lres, 1000 + rank)).cuda()
     out = torch.empty((B, 3, r, r), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((B * world, 3, r, r), dtype=torch.float32, device="cuda") if world > 1 else None
+    # SR3_FORCE_COLLECTIVE=1: the collective branch runs with one rank too (world-size-1 RCCL all-gather inside
+    # the timed region, exactly as at N > 1) — exercises librccl on a single-GPU box
+    collective = world > 1 or distm.force_collective()
+    gathered = torch.empty((B * world, 3, r, r), dtype=torch.float32, device="cuda") if collective else None
 
     def run_steps(n, t_start):
         t = t_start
@@ -184,7 +200,7 @@ def main():
         return t
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -195,17 +211,19 @@ def main():
     t_next = run_steps(K, t_next)
     eng.sample_end(out.data_ptr())
     eng.synchronize()        # explicit: the library may run on its own stream, the collective must see `out`
-    if world > 1:
+    if collective:
         if backend == "nccl":
             dist.all_gather_into_tensor(gathered, out)
         else:
             gathered = distm.all_gather_images(out.cpu(), B * world)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        if world == 1 and rank == 0 and backend == "nccl":
+            assert torch.equal(gathered, out), "world-size-1 all-gather must be the identity"
     sec_per_step = dt / K
 
     # ---- roofline of the dominant kernel family (rank 0): same K steps, HIP events per launch
@@ -276,7 +294,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "T": T,
                        "gflop_per_image_step": graph.flops_per_image(cfg, r, r) / 1e9,
                        "step": "one p_sample step (UNet forward + DDPM update) over the per-GPU batch",
-                       "parallelism": f"batch-sharded x{world}, one all-gather at the end"},
+                       "parallelism": f"batch-sharded x{world}, one all-gather at the end" +
+                                      (" (SR3_FORCE_COLLECTIVE: world-size-1 RCCL all-gather executed)" if collective and world == 1 else "")},
             "roofline": roof,
             "alt_precision": alt,
         }
@@ -287,7 +306,7 @@ def main():
             res["cpu_baseline"] = base
             res["parity"] = parity
         print(json.dumps(res, allow_nan=False), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

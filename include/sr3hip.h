@@ -55,9 +55,21 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out);
 void sr3_destroy(sr3_ctx *ctx);
 /* message of the last failing call on this thread ("" if none) */
 const char *sr3_last_error(void);
+/* Return codes: 0 = ok, < 0 = error (sr3_last_error), and one positive "ok, with a warning" code:
+ * the call's result is complete and valid, but the split-f16 arithmetic left its range and (part of) the
+ * call was recomputed in exact f32 — message via sr3_last_warning(). See sr3_set_range_policy. */
+#define SR3_OK_F32_FALLBACK 1
+const char *sr3_last_warning(void);
 /* work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) */
 int sr3_set_stream(sr3_ctx *ctx, void *hip_stream);
 int sr3_synchronize(sr3_ctx *ctx);
+/* Device-side ordering against another stream of the host (no host synchronisation): the context's stream
+ * waits for everything enqueued so far on `other_stream` / `other_stream` waits for everything enqueued so far
+ * on the context's stream. (A host that keeps its tensors on its own stream — torch's default stream cannot
+ * be captured into a hipGraph, so the library then runs on its own stream — calls the first before handing
+ * inputs over and the second before reading results.) */
+int sr3_wait_for_stream(sr3_ctx *ctx, void *other_stream);
+int sr3_stream_wait_for_ctx(sr3_ctx *ctx, void *other_stream);
 /* Arithmetic of the convolutions: 0 = exact f32 on v_mfma_f32_32x32x2_f32 (default; bit-faithful
  * fp32 products), 1 = split-f16 ("f16x3"): operands stored as hi + lo halfs, three
  * v_mfma_f32_32x32x16_f16 per product with fp32 accumulation — fp32-equivalent accuracy (error of
@@ -104,8 +116,8 @@ int sr3_set_schedule(sr3_ctx *ctx, int T, const float *noise_level, const float 
  *   out_dev    [B,C,H,W] final images (every image, not only ret_img[-1])
  *   frames_dev NULL or [n_frames,B,C,H,W]: the image after every step i with i % sample_inter == 0
  *              (:192,209-211), sample_inter = 1 | (T/10); n_frames = sr3_num_frames(ctx)
- * Stream-ordered. In f32 mode it returns after enqueueing; in split-f16 mode it synchronises at the
- * end to read the range-check flag (sr3_range_check). */
+ * Stream-ordered. In f32 mode it returns after enqueueing; in split-f16 mode it synchronises every
+ * T/10 steps and at the end to read the range-check flag (see sr3_range_check below). */
 int sr3_sample(sr3_ctx *ctx, const float *cond_dev, int B, int H, int W, const float *noise_dev,
                uint64_t seed, uint64_t image_offset, float *out_dev, float *frames_dev);
 int sr3_num_frames(sr3_ctx *ctx);
@@ -118,12 +130,23 @@ int sr3_sample_step(sr3_ctx *ctx, int t, const float *noise_slab_dev);
 int sr3_sample_end(sr3_ctx *ctx, float *out_dev);
 /* Range check of the split-f16 arithmetic (sr3_set_precision(ctx, 1)): the reference computes in
  * fp32 (diffusion.py:164-180, unet.py:235-265) and has no such limit, so a value that does not fit
- * the hi + lo fp16 operand format (|v| > 65504) must never pass silently. Every kernel that stores
- * that format raises a device flag instead of clamping; sr3_sample_end, sr3_sample and
- * sr3_unet_forward synchronise, read the flag and FAIL (the message names the f32 mode as the
- * remedy). sr3_range_check does the same on demand between sr3_sample_step calls: 0 = in range,
- * <0 = overflow since the last check (flag cleared). Synchronises the stream. */
+ * the hi + lo fp16 operand format (|v| > 65504) must never pass silently. The kernels that store
+ * that format in the UNet body (conv epilogues and split-K reduce, GroupNorm apply, attention, state
+ * packing) raise a device flag instead of clamping.
+ *   sr3_unet_forward, sr3_sample — the calls that own their inputs — FINISH the call like the reference would:
+ *     sr3_unet_forward evaluates the forward again in exact f32; sr3_sample reads the flag every
+ *     T/10 steps (one stream synchronisation each), keeps a copy of the sampler state of the last
+ *     in-range boundary and, when the flag trips, replays from that boundary to the end in exact f32
+ *     (noise draws and frame slots are functions of t, so the replay is exact). Both then return
+ *     SR3_OK_F32_FALLBACK (> 0) with sr3_last_warning() set; sr3_fallback_calls counts them.
+ *   sr3_set_range_policy(ctx, 1) ("strict") restores the failing behaviour: those calls return < 0
+ *     and the message names the f32 mode as the remedy.
+ *   sr3_sample_end (step API: the caller owns the noise slabs, the library cannot replay) always
+ *     fails on overflow; sr3_range_check does the same on demand between sr3_sample_step calls:
+ *     0 = in range, < 0 = overflow since the last check (flag cleared). Both synchronise the stream. */
 int sr3_range_check(sr3_ctx *ctx);
+int sr3_set_range_policy(sr3_ctx *ctx, int strict);
+int sr3_fallback_calls(sr3_ctx *ctx);
 
 /* The documented CPU twin of the device RNG is oracle/philox.py; this dumps the device stream for
  * comparison: n floats of draw `draw` for image `image`. */

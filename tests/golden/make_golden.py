@@ -130,9 +130,11 @@ def gen_unet(name, cfg, B, r, seed, with_taps=False):
     print(f"    ({time.time() - t0:.1f}s, eps std {eps.std():.3f})")
 
 
-def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True, frame_stride=1):
+def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True, frame_stride=1, with_last=True):
     """frame_stride > 1 (large fixtures): the intermediate frames are stored sub-sampled
-    ([..., ::s, ::s]) as `frames_sub`; the final images (`final`, every pixel) and `last` stay whole."""
+    ([..., ::s, ::s]) as `frames_sub`; the final images (`final`, every pixel) and `last` stay whole.
+    with_last=False (the T = 1000 fixture: one reference run is ~5 min here) skips the second,
+    `continous=False` run of the reference; no `last` array is stored then."""
     t0 = time.time()
     netG = build_ref(cfg, sched, seed, conditional)
     T = sched["n_timestep"]
@@ -144,8 +146,10 @@ def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True, frame_stride=
         with NoiseFeed(noise) as nf:
             ret = netG.super_resolution(torch.from_numpy(cond), continous=True).numpy()
             assert nf.k == T, nf.k
-        with NoiseFeed(noise):
-            last = netG.super_resolution(torch.from_numpy(cond), continous=False).numpy()
+        last = None
+        if with_last:
+            with NoiseFeed(noise):
+                last = netG.super_resolution(torch.from_numpy(cond), continous=False).numpy()
     else:
         with NoiseFeed(noise) as nf:
             ret = netG.sample(batch_size=B, continous=True).numpy()
@@ -155,9 +159,11 @@ def gen_sampler(name, cfg, sched, B, r, l, seed, conditional=True, frame_stride=
     if frame_stride > 1:
         nf = ret.shape[0] // B - 1
         fr = ret[B:].reshape(nf, B, 3, r, r)
-        arrs.update(frames_sub=fr[..., ::frame_stride, ::frame_stride].copy(), final=fr[-1].copy(), last=last,
+        arrs.update(frames_sub=fr[..., ::frame_stride, ::frame_stride].copy(), final=fr[-1].copy(),
                     meta=meta(cfg, B=B, r=r, l=l, seed=seed, conditional=conditional, schedule=sched,
                               frame_stride=frame_stride))
+        if last is not None:
+            arrs["last"] = last
     else:
         arrs.update(ret_img=ret, last=last,
                     meta=meta(cfg, B=B, r=r, l=l, seed=seed, conditional=conditional, schedule=sched))
@@ -205,3 +211,11 @@ if __name__ == "__main__":
         # yml-literal UNet; intermediate frames stored sub-sampled (every 4th pixel per axis)
         print("sampler config 5 (128x128, T=100)")
         gen_sampler("sampler_cfg5_32_128.npz", synth.yml_unet_config(224), s100, B=2, r=128, l=32, seed=9, frame_stride=4)
+    if only("sampler_cfg2_16_128_T1000.npz"):
+        # BASELINE.json config 2, the benchmarked workload, over its FULL horizon: 16 -> 128, yml-literal UNet,
+        # T = 1000 linear 1e-6..1e-2 (config/sr_sr3_VGGF2_8_128_model3.yml's n_timestep: 1000), B = 1;
+        # diffusion.py:189-215 run once (continous=True); intermediate frames sub-sampled (every 4th pixel)
+        s1000 = {"schedule": "linear", "n_timestep": 1000, "linear_start": 1e-6, "linear_end": 1e-2}
+        print("sampler config 2 (16 -> 128, T=1000)")
+        gen_sampler("sampler_cfg2_16_128_T1000.npz", synth.yml_unet_config(224), s1000, B=1, r=128, l=16, seed=10,
+                    frame_stride=4, with_last=False)

@@ -67,6 +67,7 @@ def test_split_f16_overflow_is_detected_not_clamped():
     x = rs.standard_normal((2, 6, 16, 16)).astype(np.float32)
     nl = np.array([0.3, 0.7], np.float32)
     e = _engine(cfg, sd, "f16x3")
+    e.set_range_policy(True)        # strict: fail the call (round 3's default finishes it in f32, tests/test_gpu_round3.py)
     with pytest.raises(Sr3Error, match="fp16 range"):
         e.unet_forward_np(x, nl)
     # the flag is cleared by the failing call: an in-range input on the same context works again

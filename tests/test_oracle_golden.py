@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import sr3_oracle as oracle
+import sr3_oracle_aten as aten
 from conftest import cfg_from_meta, load_golden, pkg
 
 synth = pkg("synth")
@@ -88,6 +89,75 @@ def test_sampler_128px_head_matches_reference():
             np.testing.assert_allclose(x[..., ::st, ::st], g["frames_sub"][f], atol=1e-4, rtol=0, err_msg=f"frame {f} (t={t})")
             f += 1
     assert f == 2
+
+
+@pytest.mark.parametrize("name,tol", [("unet_tiny.npz", 2e-5), ("unet_yml224_r16.npz", 2e-5),
+                                      ("unet_yml128_r32.npz", 2e-5), ("unet_yml224_r128.npz", 2e-5),
+                                      ("unet_yml128_r128.npz", 2e-5)])
+def test_aten_unet_forward_matches_reference(name, tol):
+    """oracle/sr3_oracle_aten.py (torch CPU operators; bench.py's `cpu_baseline` leg) against the same
+    reference-made fixtures as the numpy oracle."""
+    import torch
+    g = load_golden(name)
+    cfg = cfg_from_meta(g["meta"])
+    sd = aten.to_torch_state(synth.synth_state_dict(cfg, g["meta"]["seed"]))
+    taps = {}
+    with torch.no_grad():
+        eps = aten.unet_forward(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["noise_level"]), taps=taps).numpy()
+    for k in g:
+        if k.startswith("tap."):
+            np.testing.assert_allclose(taps[k[4:]], g[k], atol=tol, rtol=0, err_msg=k)
+    np.testing.assert_allclose(eps, g["eps"], atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["sampler_tiny.npz", "sampler_uncond_tiny.npz", "sampler_cfg1_8_16.npz"])
+def test_aten_sampler_matches_reference(name):
+    g = load_golden(name)
+    m = g["meta"]
+    cfg = cfg_from_meta(m)
+    sd = synth.synth_state_dict(cfg, m["seed"])
+    sch = aten.noise_schedule(m["schedule"])
+    B, r, T = m["B"], m["r"], m["schedule"]["n_timestep"]
+    noise = synth.synth_noise(T, B, 3, r, r, m["seed"])
+    cond = g["cond"] if m["conditional"] else None
+    final, frames = aten.p_sample_loop(sd, cfg, sch, cond, noise)
+    first = cond if cond is not None else noise[0]
+    ret = np.concatenate([first, frames.reshape(-1, *frames.shape[2:])], axis=0)
+    np.testing.assert_allclose(ret, g["ret_img"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(final[-1], g["last"], atol=1e-4, rtol=0)
+
+
+def test_sampler_cfg2_T1000_head_matches_reference():
+    """BASELINE config 2 (the benchmarked workload: 16 -> 128, yml-literal UNet, T = 1000, B = 1) pinned to
+    the reference over its full horizon by tests/golden/sampler_cfg2_16_128_T1000.npz; the whole loop is the
+    GPU tests' job (tests/test_gpu_round3.py). Here both CPU oracles reproduce its head: the aten oracle runs
+    to the first recorded frame (t = 999 ... 909 — frames follow i % (1 | T // 10) == 0 with si = 101,
+    diffusion.py:192,210 — 91 steps), the numpy oracle the first 6 steps against the aten state."""
+    import torch
+    g = load_golden("sampler_cfg2_16_128_T1000.npz")
+    m = g["meta"]
+    cfg = cfg_from_meta(m)
+    sd = synth.synth_state_dict(cfg, m["seed"])
+    sch = oracle.noise_schedule(m["schedule"])
+    B, r, T, st = m["B"], m["r"], m["schedule"]["n_timestep"], m["frame_stride"]
+    assert (B, r, T, m["l"]) == (1, 128, 1000, 16)
+    noise = synth.synth_noise(T, B, 3, r, r, m["seed"])
+    np.testing.assert_array_equal(g["cond"], synth.synth_cond(B, r, m["l"], m["seed"]))
+    assert g["frames_sub"].shape == (10, B, 3, r // st, r // st) and g["final"].shape == (B, 3, r, r)
+    np.testing.assert_array_equal(g["final"][..., ::st, ::st], g["frames_sub"][-1])
+    si = 1 | (T // 10)
+    tsd = aten.to_torch_state(sd)
+    tc = torch.from_numpy(g["cond"])
+    x = torch.from_numpy(noise[0].copy())
+    xn = noise[0]
+    with torch.no_grad():
+        for k, t in enumerate(range(T - 1, T - 1 - 91, -1)):
+            x = aten.p_sample(tsd, cfg, sch, x, t, tc, torch.from_numpy(noise[k + 1].copy()))
+            if k < 6:
+                xn = oracle.p_sample(sd, cfg, sch, xn, t, g["cond"], noise[k + 1])
+                np.testing.assert_allclose(xn, x.numpy(), atol=2e-5, rtol=0, err_msg=f"numpy vs aten oracle at t={t}")
+    assert t % si == 0
+    np.testing.assert_allclose(x.numpy()[..., ::st, ::st], g["frames_sub"][0], atol=1e-4, rtol=0)
 
 
 def test_pil_bicubic_restatement_bit_exact():
