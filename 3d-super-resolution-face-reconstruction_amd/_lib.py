@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsr3hip.so")
+# SR3_LIB: another build of the same C-ABI (development: the -DSR3_EXPERIMENTS library of build.py --experiments)
+LIB_PATH = os.environ.get("SR3_LIB") or os.path.join(HERE, "libsr3hip.so")
 
 SR3_MAX_MULTS = 8
 SR3_MAX_ATTN_RES = 8

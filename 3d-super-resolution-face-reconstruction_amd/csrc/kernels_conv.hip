@@ -238,11 +238,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 // (flag in colbias[BN]); otherwise bias only and the per-image part is gathered per row.
 // QRED (persistent kernel): the four row groups of a wave are added by lane exchange first, only lanes q == 0
 // write [wm][column] entries (a quarter of the staging space) and the caller does the barrier
-template <int BM, int BN, int WGM, int WGN, int MT, int NT, bool QRED = false>
+// GNF (producer-side GroupNorm of the output, ConvParams::gnf_*): the column statistics go out FIRST (phase 6 moves in
+// front of the stores), the wave then sits through the four barriers of gnf_producer_tail, picks up scale / shift of its
+// columns from LDS, applies swish(scale * v + shift) to the accumulators and stores them as the split-f16 tensor only.
+template <int BM, int BN, int WGM, int WGN, int MT, int NT, bool QRED = false, bool GNF = false>
 __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc)[MT][NT], float *smem,
                                                 const int *rowpix, const int *rowimg, int m0, int n0, int M, int wm,
                                                 int wn, int l16, int q, const float *colbias) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
+    static_assert(!(GNF && QRED), "the persistent experiment has no producer-side GroupNorm");
     const unsigned Cout = (unsigned)p.out.C;
     const bool one_img = reinterpret_cast<const int *>(colbias)[BN] != 0;
     const unsigned ncol = (unsigned)(n0 + wn * WN + l16);       // column of nt = 0; + 16 per nt
@@ -303,8 +307,43 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
             }
         }
     }
+    if constexpr (GNF) {
+        // 6'. statistics of the values block2's GroupNorm sees (bias and FeatureWiseAffine bias included), then the
+        //     hand-off (gnf_producer_tail: barriers A, A2, A3, Y, X1) and the normalisation in registers
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double st1 = 0.0, st2 = 0.0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = (double)acc[mt][nt][j];
+                    st1 += v; st2 = fma(v, v, st2);
+                }
+            reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();        // A: column sums staged
+        __syncthreads();        // A2: this block's slice is on its way to memory
+        __syncthreads();        // A3: arrival counted
+        __syncthreads();        // Y: (last block: slices folded | others: group ready)
+        __syncthreads();        // X1: scale / shift of this N-tile in LDS
+        const float2 *ab_lds = reinterpret_cast<const float2 *>(smem + WGM * 4 * BN * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float2 ab = ab_lds[wn * WN + nt * 16 + l16];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = fmaf(ab.x, acc[mt][nt][j], ab.y);
+                    acc[mt][nt][j] = x * __frcp_rn(1.0f + __expf(-x));      // Swish (unet.py:53-55), as gn_apply does it
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     // 4. fp32 output (32-bit byte offsets: every tensor is < 4 GiB)
-    if (p.out_f32) {
+    if (!GNF && p.out_f32) {
         char *obase = reinterpret_cast<char *>(p.out.p);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -342,7 +381,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
         if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
     }
     // 6. fused GroupNorm statistics of the stored values: fp64 column sums, handed to the producers
-    if (p.stats != nullptr) {
+    if (!GNF && p.stats != nullptr) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             double st1 = 0.0, st2 = 0.0;
@@ -381,6 +420,124 @@ __device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const f
         const int n = m0 / HWo, slice = p.stats_slice0 + (m0 - n * HWo) / BM;
         double *o = p.stats + (((size_t)n * p.stats_slices + slice) * Cout + n0 + col) * 2;
         o[0] = a; o[1] = b;
+    }
+}
+
+// Producer side of the producer-side GroupNorm (ConvParams::gnf_*), run by the block's 256 producer threads while the
+// consumer waves sit in the matching barriers of conv_epilogue16<..., GNF>. NSL = staged entries per column.
+// Hand-off forms (MI355X_MICROARCH.md, inter-workgroup visibility): every byte that crosses blocks is written by a
+// write-through (sc1) store and read by a cache-bypassing (sc1) global load; every storing wave waits vmcnt(0), then a
+// workgroup barrier, then ONE lane adds to the group's counter (agent scope). The counter of a group of G blocks runs
+// 0 -> G (arrivals; the add that returns G - 1 marks the last block) -> 2G (the last block's "ready", after its
+// scale / shift stores have completed) -> 3G (departures: every block adds 1 after it has fetched scale / shift; the
+// add that returns 3G - 1 stores 0, ready for the next launch — nobody polls any more by then).
+// No wait can hang by construction: a block only waits for blocks of its own group, which launch_conv orders so that
+// they are dispatched together (see conv_gnf_supported); should the hardware ever dispatch differently, the poll gives
+// up after ~2 s, raises SR3_FLAG_GNF_TIMEOUT in *ovf (the API call fails) and the grid drains.
+typedef unsigned __attribute__((address_space(1))) *gnf_cnt_ptr;
+typedef const double __attribute__((address_space(1))) *gnf_cdbl_ptr;
+typedef double __attribute__((address_space(1))) *gnf_dbl_ptr;
+typedef const float __attribute__((address_space(1))) *gnf_cflt_ptr;
+typedef float __attribute__((address_space(1))) *gnf_flt_ptr;
+template <int BM, int BN, int NSL>
+__device__ __forceinline__ void gnf_producer_tail(const ConvParams &p, float *smem, int m0, int n0, int HWo, int tid) {
+    const double2 *red = reinterpret_cast<const double2 *>(smem);
+    float2 *ab_lds = reinterpret_cast<float2 *>(smem + NSL * BN * 4);                  // [BN]
+    double2 *fin = reinterpret_cast<double2 *>(smem + NSL * BN * 4 + 2 * BN);          // [256 / BN][BN]
+    const int Cout = p.out.C;
+    const int img = m0 / HWo, TMI = HWo / BM, slice = (m0 - img * HWo) / BM;
+    const int tilesN = Cout / BN, ntile = n0 / BN;
+    const unsigned G = (unsigned)TMI;
+    // counter and ready word of the group on cache lines of their own (the pollers' loads must not queue in front of
+    // the other blocks' arrival adds)
+    gnf_cnt_ptr cnt = (gnf_cnt_ptr)(p.gnf_cnt + ((size_t)img * tilesN + ntile) * 64);
+    gnf_cnt_ptr rdy = cnt + 32;
+    __syncthreads();                                    // A: the consumers' column sums are staged
+    if (tid < BN) {
+        double a = 0, b = 0;
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) { const double2 v = red[j * BN + tid]; a += v.x; b += v.y; }
+        gnf_dbl_ptr o = (gnf_dbl_ptr)(p.stats + (((size_t)img * TMI + slice) * Cout + n0 + tid) * 2);
+        __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the slice has reached the coherence point ...
+    __syncthreads();                                    // A2: ... in every storing wave
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == G - 1u) {
+            // last arrival: every block of the group counted itself after its slice had completed
+            __hip_atomic_store(rdy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long long t0 = __builtin_amdgcn_s_memtime();
+            while (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(16);
+                if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {     // ~2.7 s of the 100 MHz counter: never in a healthy run
+                    if (p.ovf != nullptr) atomicOr(p.ovf, SR3_FLAG_GNF_TIMEOUT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();                                    // A3: all G slices of this image are complete
+    // EVERY block folds the G slices of its N-tile's channels itself (in slice order: the same bits in every block):
+    // thread (channel c, part) adds slices part, part + PARTS, ... with all its loads in flight at once. One hop less
+    // than "the last block folds and publishes" (no second flag, no scale / shift round trip).
+    constexpr int PARTS = 256 / BN;
+    {
+        const int c = tid % BN, part = tid / BN;
+        gnf_cdbl_ptr base = (gnf_cdbl_ptr)(p.stats + ((size_t)img * TMI * Cout + n0 + c) * 2);
+        const size_t sstride = (size_t)Cout * 2;
+        double sa = 0, sb = 0;
+        int sidx = part;
+        for (; sidx + 15 * PARTS < TMI; sidx += 16 * PARTS) {
+            double va[16], vb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                va[u] = __hip_atomic_load(base + (size_t)(sidx + u * PARTS) * sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vb[u] = __hip_atomic_load(base + (size_t)(sidx + u * PARTS) * sstride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { sa += va[u]; sb += vb[u]; }
+        }
+        for (; sidx + 3 * PARTS < TMI; sidx += 4 * PARTS) {
+            double va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                va[u] = __hip_atomic_load(base + (size_t)(sidx + u * PARTS) * sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vb[u] = __hip_atomic_load(base + (size_t)(sidx + u * PARTS) * sstride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sa += va[u]; sb += vb[u]; }
+        }
+        for (; sidx < TMI; sidx += PARTS) {
+            sa += __hip_atomic_load(base + (size_t)sidx * sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sb += __hip_atomic_load(base + (size_t)sidx * sstride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        fin[part * BN + c] = make_double2(sa, sb);
+    }
+    __syncthreads();                                    // Y
+    if (tid < BN) {
+        // whole groups lie inside an N-tile: channel tid adds its group's channels and parts in a fixed order
+        const int cg = Cout / p.gnf_groups, g0 = (tid / cg) * cg;
+        double sa = 0, sb = 0;
+        for (int cc = 0; cc < cg; ++cc)
+#pragma unroll
+            for (int pt = 0; pt < PARTS; ++pt) { const double2 v = fin[pt * BN + g0 + cc]; sa += v.x; sb += v.y; }
+        const double count = (double)cg * HWo;
+        const double mean = sa / count;
+        const double var = fmax(sb / count - mean * mean, 0.0);
+        const float rstd = 1.0f / sqrtf((float)var + p.gnf_eps);
+        const float sc = rstd * p.gnf_gamma[n0 + tid];
+        ab_lds[tid] = make_float2(sc, p.gnf_beta[n0 + tid] - (float)mean * sc);
+    }
+    __syncthreads();                                    // X1: scale / shift of this N-tile in LDS
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // departed
+        if (old == 2u * G - 1u) {       // every block of the group has read the slices: ready for the next launch
+            __hip_atomic_store(rdy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -779,8 +936,10 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // =================================================================================================
 // MS: MFMA shape of the consumers, 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16: same
 // FLOP per cycle, but the chip holds a higher clock on it under load — MI355X_MICROARCH.md, DVFS (7))
-template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
+// GNF: producer-side GroupNorm of the output (ConvParams::gnf_*; MS == 16 only)
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false>
 __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) void conv3x3_halo_h3(const ConvParams p_in) {
+    static_assert(!GNF || (MS == 16 && KS == 3), "producer-side GroupNorm: 3x3 convs on the 16x16x32 consumers");
     const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -810,7 +969,27 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     const int M = p.B * HWo;
     const int tilesN = (Cout + BN - 1) / BN;
     int bid = blockIdx.x;
-    {
+    if (GNF) {
+        // Block order of the producer-side GroupNorm: the blocks of one image must be dispatched together (they wait
+        // for each other), whole images per XCD so that no group straddles two XCDs' dispatch sequences.
+        //  band == 0 (an image is at most 32 blocks): XCD x = blockIdx.x & 7 takes images x, x + 8, ... one after the
+        //    other (the grid is padded to whole rounds of eight images; surplus blocks leave at once);
+        //  band > 0 (128x128-pixel level: 128 M-tiles per image): XCD x takes M-tiles [x * band, (x + 1) * band) of
+        //    EVERY image, images in order — an image is spread over the eight XCDs, band x tilesN blocks on each, and
+        //    neighbouring image rows still share an L2.
+        const int xcd = bid & 7, loc = bid >> 3, TMI = HWo / BM;
+        if (p.gnf_band > 0) {
+            const int per = p.gnf_band * tilesN;
+            const int image = loc / per, r = loc - image * per;
+            const int j = r / tilesN;
+            bid = (image * TMI + xcd * p.gnf_band + j) * tilesN + (r - j * tilesN);
+        } else {
+            const int per = TMI * tilesN;
+            const int image = (loc / per) * 8 + xcd;
+            if (image >= p.B) return;
+            bid = image * per + (loc % per);
+        }
+    } else {
         const int nwg = gridDim.x;
         const int xcd = bid & 7, loc = bid >> 3;
         const int qq = nwg >> 3, rr = nwg & 7;
@@ -1007,6 +1186,10 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             ++ga;
         }
         __syncthreads();
+        if constexpr (GNF) {
+            gnf_producer_tail<BM, BN, WGM * 4>(p, smem, m0, n0, HWo, tid);
+            return;
+        }
         if (p.stats != nullptr) producer_stats_tail<BM, BN, WGM, MS == 16 ? 4 : 2>(p, smem, m0, n0, HWo);
         return;
     }
@@ -1219,7 +1402,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] *= p.w_unscale;
-        conv_epilogue16<BM, BN, WGM, WGN, MT, NT>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, l16, q, colbias);
+        conv_epilogue16<BM, BN, WGM, WGN, MT, NT, false, GNF>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, l16, q, colbias);
         return;
     }
     const int li = lane & 31, lh = lane >> 5;
@@ -1704,19 +1887,23 @@ void launch_halo_pt(const ConvParams &p, hipStream_t s) {
 
 #endif  // SR3_EXPERIMENTS
 
-template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS>
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false>
 void launch_halo(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr int RA = (BM + (KS - 1) * (BM / SEGMIN) + 7) / 8 * 8;
     constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM + BN + 4) * sizeof(float);
-    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS>;
+    // (the GroupNorm hand-off stages its sums, scale / shift and the fold scratch in the rings, free after the K loop)
+    static_assert(!GNF || ((size_t)WGM * 4 * BN * 16 + BN * 8 + 4096 + 16 <= ((size_t)2 * RA * ROWF + 2 * BN * ROWF) * sizeof(float)), "GNF staging fits the rings");
+    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS, GNF>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int M = p.B * p.Hout * p.Wout;
-    hipLaunchKernelGGL(kern, dim3((M / BM) * ((p.out.C + BN - 1) / BN), 1, p.phases), dim3(512), lds, s, p);
+    int grid = (M / BM) * ((p.out.C + BN - 1) / BN);
+    if (GNF && p.gnf_band == 0) grid = (p.B + 7) / 8 * 8 * ((p.Hout * p.Wout) / BM) * (p.out.C / BN);   // whole rounds of eight images
+    hipLaunchKernelGGL(kern, dim3(grid, 1, p.phases), dim3(512), lds, s, p);
 }
 
 // consumer MFMA shape of the halo kernels: 16x16x32 with the four consumer waves stacked along M
@@ -1925,6 +2112,54 @@ bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases) {
     return t == 2 && (HWo % bm[t]) == 0 && (Cout % bn[t]) == 0 && tiles * phases <= CONV_TILE_COUNTERS;
 }
 
+// Producer-side GroupNorm (ConvParams::gnf_*): which halo kernel would run it — 0 none, 1 the 128x64 tile, 2 the 128x128
+// tile with row segments of 32+ pixels, 3 the 128x128 tile with shorter segments.
+// EXPERIMENT (libsr3hip_exp.so, SR3_GNF=1 [SR3_GNF_MAX_HW=pixels]): correct (all sampler / UNet / full-size tests pass with
+// it) but it does not pay — the cross-CU hand-off costs a block about what the saved apply pass costs the chip
+// (profiles/README.md finding 54), and its liveness rests on the observed dispatch order. The product library never
+// takes this path.
+static int gnf_kernel_choice(const ConvParams &p, int groups) {
+#ifndef SR3_EXPERIMENTS
+    (void)p; (void)groups;
+    return 0;
+#else
+    static const int on = getenv("SR3_GNF") ? atoi(getenv("SR3_GNF")) : 0;
+    if (!on || !halo_mfma16() || p.prec != 1 || p.ks != 3 || p.stride != 1 || p.up2 || p.phases > 1 || groups <= 0) return 0;
+    if (p.resid.p != nullptr || p.in2.p != nullptr || p.stats == nullptr) return 0;
+    const int Cout = p.out.C, HWo = p.Hout * p.Wout;
+    const long M = (long)p.B * HWo;
+    if ((Cout % groups) != 0 || (HWo % 128) != 0) return 0;             // whole 128-row tiles inside one image
+    const int cg = Cout / groups;
+    const int Cin = p.in0.C + (p.in1.p ? p.in1.C : 0);
+    if (conv_splits(M, Cout, Cin) > 1) return 0;
+    int which = 0, bn = 0;
+    switch (conv_tile_choice(M, Cout)) {
+    case 1: if (halo_ok(p, 128, 32, 64)) { which = 1; bn = 64; } break;
+    case 3:
+        if (halo_ok(p, 128, 32, 128)) { which = 2; bn = 128; }
+        else if (halo_ok(p, 128, 8, 128)) { which = 3; bn = 128; }
+        break;
+    default: break;
+    }
+    if (!which || (bn % cg) != 0 || p.stats_slices != HWo / 128) return 0;
+    if ((long)p.B * (Cout / bn) > CONV_GNF_COUNTERS) return 0;
+    static const int max_hw = getenv("SR3_GNF_MAX_HW") ? atoi(getenv("SR3_GNF_MAX_HW")) : (1 << 30);   // A/B: only images of at most this many pixels
+    if (HWo > max_hw) return 0;
+    // every (image, N-tile) group of TMI blocks must be able to be resident together: the standard block order keeps an
+    // image's TMI x tilesN blocks on one XCD (32 CUs x 2 blocks at least); larger images use the band order, which
+    // needs TMI to divide over the eight XCDs and a grid the round-robin deals evenly
+    const int TMI = HWo / 128, tilesN = Cout / bn;
+    if (TMI * tilesN > 32 && (TMI % 8) != 0) return 0;
+    if (TMI * tilesN > 32 && (TMI / 8) * tilesN > 32) return 0;
+    return which;
+#endif
+}
+static int gnf_band_for(const ConvParams &p, int which) {
+    const int HWo = p.Hout * p.Wout, TMI = HWo / 128, tilesN = p.out.C / (which == 1 ? 64 : 128);
+    return TMI * tilesN > 32 ? TMI / 8 : 0;
+}
+bool conv_gnf_supported(const ConvParams &p, int groups) { return gnf_kernel_choice(p, groups) != 0; }
+
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     if (p_in.up2) { launch_conv_up2(p_in, s); return; }     // weights must be in phase form (make_up2_phase_weights)
     ConvParams p = p_in;
@@ -1949,6 +2184,18 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         if (p.stats && splitk_stats_slices(HWo, p.out.C) > 0) reduce_stats = p.stats;
         p.stats = nullptr;
     }
+#ifdef SR3_EXPERIMENTS
+    if (p.gnf_gamma != nullptr) {
+        // producer-side GroupNorm: the caller asked conv_gnf_supported() first
+        const int which = gnf_kernel_choice(p, p.gnf_groups);
+        if (which == 0) { fprintf(stderr, "sr3: internal: producer-side GroupNorm requested for an unsupported conv\n"); abort(); }
+        p.gnf_band = gnf_band_for(p, which);
+        if (which == 1) launch_halo<128, 64, 4, 1, 32, 3, 16, true>(p, s);
+        else if (which == 2) launch_halo<128, 128, 4, 1, 32, 3, 16, true>(p, s);
+        else launch_halo<128, 128, 4, 1, 8, 3, 16, true>(p, s);
+        return;
+    }
+#endif
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:

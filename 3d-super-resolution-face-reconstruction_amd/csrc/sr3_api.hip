@@ -140,6 +140,8 @@ struct sr3_ctx {
     float *ckpt = nullptr;              // sr3_sample: NCHW copy of the sampler state at the last clean checkpoint
     size_t ckpt_floats = 0;
     unsigned *tile_cnt = nullptr;       // ConvParams::tile_cnt: arrival counters of the in-place split-K convs (zero between launches)
+    unsigned *gnf_cnt = nullptr;        // ConvParams::gnf_cnt: group counters of the producer-side GroupNorm (zero between launches)
+    float *gnf_ab = nullptr;            // ConvParams::gnf_ab: [B][c_max][2] (workspace)
 
     // workspace for one (B, H, W)
     int wB = 0, wH = 0, wW = 0;
@@ -560,6 +562,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     const uint64_t o_qkv = cv.take(max_qkv), o_ao = cv.take(max_ao), o_vt = cv.take(max_vt);
     const uint64_t o_part = cv.take(max_part);
     const uint64_t o_gs = cv.take((uint64_t)B * c->c_max), o_gh = cv.take((uint64_t)B * c->c_max);
+    const uint64_t o_gab = cv.take((uint64_t)B * c->c_max * 2);
     const uint64_t o_gp = cv.take(gn_workspace_floats(B, c->c_max));
     const uint64_t o_te = cv.take((uint64_t)B * g.inner_channel);
     const uint64_t o_cb = cv.take((uint64_t)B * c->nf_total);
@@ -608,6 +611,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     c->qkvb = at(o_qkv); c->aob = at(o_ao); c->vtb = at(o_vt);
     c->part = max_part ? at(o_part) : nullptr;
     c->gscale = at(o_gs); c->gshift = at(o_gh); c->gpart = at(o_gp);
+    c->gnf_ab = at(o_gab);
     c->temb = at(o_te); c->cbias = at(o_cb);
     c->all_fused = all_fused;
     c->wB = B; c->wH = H; c->wW = W;
@@ -652,7 +656,8 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
               const float *chan_bias, const TDesc &resid, const TDesc &out, bool activated = false,
               const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
               const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc(),
-              bool out_f32 = true, bool resid_split = false, const float *w2_raw = nullptr) {
+              bool out_f32 = true, bool resid_split = false, const float *w2_raw = nullptr, const GNRef *gnf = nullptr,
+              bool *gnf_done = nullptr) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
@@ -677,13 +682,25 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
         p.in2 = in2;                    // identity skip as extra K-steps (ResBlock::ident_w)
         p.w2 = w2_raw;
     }
+    bool use_gnf = false;
+    if (gnf && p.prec == 1 && p.out_split.p && conv_gnf_supported(p, c->cfg.norm_groups)) {
+        // producer-side GroupNorm: the conv normalises its own output and writes swish(scale * h + shift) as out_split
+        p.gnf_gamma = c->params[gnf->gamma].dev; p.gnf_beta = c->params[gnf->beta].dev;
+        p.gnf_groups = c->cfg.norm_groups; p.gnf_eps = 1e-5f;
+        p.gnf_cnt = c->gnf_cnt; p.gnf_ab = c->gnf_ab;
+        p.out_f32 = 0;
+        use_gnf = true;
+    }
+    if (gnf_done) *gnf_done = use_gnf;
+    if (gnf && !use_gnf) { p.out_split = TDesc(); p.out_f32 = 1; }   // the caller runs the apply pass on the fp32 output
     c->pbegin(F_CONV);
     if (up2) launch_conv_up2(p, c->stream);
     else launch_conv(p, c->stream);
     if (c->prof) {
         char tag[160];
-        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d fused1x1:%d prec%d", cv.ks, stride,
-                 up2, out.H, out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, cv2 ? cv2->cin : 0, p.prec);
+        snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d fused1x1:%d prec%d%s", cv.ks, stride,
+                 up2, out.H, out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, cv2 ? cv2->cin : 0, p.prec,
+                 use_gnf ? " +gn" : "");
         c->pend(2.0 * (double)B * out.H * out.W * cv.cout * ((double)(cv.ks * cv.ks) * cv.cin + (cv2 ? cv2->cin : 0)), tag);
     }
 }
@@ -708,8 +725,12 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     const bool direct = rb.has_res && xr.p && (!skip.p || skr.p);
     run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, m.act1, sx, ss,
                rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0));
-    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1);
-    run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef());
+    // block1's conv + FeatureWiseAffine bias, then block2's GroupNorm + Swish: inside the conv where the producer-side
+    // form applies (h1 then never exists: the conv writes act2), else as the apply pass over the fp32 h1
+    bool gn2_done = false;
+    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1,
+             c->prec ? m.act2 : kNone, kNone, true, false, nullptr, c->prec && !c->no_fused_stats ? &rb.gn2 : nullptr, &gn2_done);
+    if (!gn2_done) run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef());
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
     // K-steps | + x as residual when the block keeps its width]
     const TDesc tw = rb.attn ? kNone : m.out_s;      // with attention the out-projection writes the module output
@@ -942,7 +963,11 @@ int range_read(sr3_ctx *c) {
     HIP_OK(hipMemcpyAsync(c->h_ovf, c->d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     if (*c->h_ovf == 0) return 0;
+    const int v = *c->h_ovf;
     HIP_OK(hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream));
+    if (v & SR3_FLAG_GNF_TIMEOUT)
+        return fail("internal: a producer-side GroupNorm wait timed out (the blocks of an image were not dispatched "
+                    "together); the result is invalid — set SR3_NO_GNF=1 to use the separate apply pass and report this");
     return 1;
 }
 
@@ -1077,6 +1102,8 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
     if (hipMalloc(&c->d_ovf, sizeof(int)) != hipSuccess || hipMemset(c->d_ovf, 0, sizeof(int)) != hipSuccess ||
         hipMalloc(&c->tile_cnt, CONV_TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
         hipMemset(c->tile_cnt, 0, CONV_TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc(&c->gnf_cnt, (size_t)CONV_GNF_COUNTERS * 64 * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(c->gnf_cnt, 0, (size_t)CONV_GNF_COUNTERS * 64 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_ovf), sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sr3_destroy(c);
         return fail("allocating the range-check flag failed");
@@ -1109,6 +1136,7 @@ void sr3_destroy(sr3_ctx *c) {
     if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->ckpt) (void)hipFree(c->ckpt);
     if (c->tile_cnt) (void)hipFree(c->tile_cnt);
+    if (c->gnf_cnt) (void)hipFree(c->gnf_cnt);
     if (c->h_ovf) (void)hipHostFree(c->h_ovf);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     if (c->d_step) (void)hipFree(c->d_step);

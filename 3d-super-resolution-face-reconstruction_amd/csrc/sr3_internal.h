@@ -83,8 +83,27 @@ struct ConvParams {
     // split-f16 range check: any value stored in the split format (out_split) with |v| > 65504 (or
     // non-finite) sets *ovf = 1; the API call that ran the launch then fails (never a silent clamp)
     int *ovf = nullptr;
+    // Producer-side GroupNorm of the OUTPUT (gnf_gamma != nullptr): the output h of a ResnetBlock's first conv is read
+    // by nothing but block2's GroupNorm + Swish (unet.py:105-110, 84-87), so the conv normalises it ITSELF and stores
+    // swish(scale * h + shift) straight in the next conv's operand format (out_split = that conv's activated input,
+    // out_f32 = 0): h never reaches memory and no apply pass runs. Inside the launch the blocks of one (image, N-tile)
+    // group — they hold whole GroupNorm groups of that image between them — publish their fp64 partial statistics
+    // (ConvParams::stats, one slice per M-tile, write-through stores), count themselves on gnf_cnt[image * tilesN + nt];
+    // the block that arrives last folds the slices in slice order (bit-identical whichever block it is), publishes
+    // scale / shift in gnf_ab and signals; the others poll the counter (one lane, s_sleep) and fetch gnf_ab.
+    // Requirements (conv_gnf_supported): split-f16 x-halo kernel with 16x16x32 consumers, whole 128-row tiles inside one
+    // image, whole groups inside an N-tile, no split-K, and every group's blocks co-resident on their XCD (the block
+    // order is chosen for it: gnf_band).
+    const float *gnf_gamma = nullptr, *gnf_beta = nullptr;   // [Cout] of the GroupNorm that FOLLOWS this conv
+    int gnf_groups = 0;
+    float gnf_eps = 1e-5f;
+    unsigned *gnf_cnt = nullptr;       // per (image, N-tile) 64 words: [0] counter, [32] ready word (two cache lines), zero between launches
+    float *gnf_ab = nullptr;           // [B][Cout][2] scale | shift
+    int gnf_band = 0;                  // > 0: M-tiles of an image per XCD (band block order, set by launch_conv)
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
+// value written to *ConvParams::ovf when a producer-side GroupNorm wait gives up (the dispatch-order assumption failed)
+constexpr int SR3_FLAG_GNF_TIMEOUT = 2;
 // largest magnitude the split-f16 format (hi + lo, both fp16) can hold
 constexpr float SPLIT_F16_MAX = 65504.0f;
 
@@ -124,6 +143,10 @@ int conv_splits(long M, int Cout, int Cin);
 // true when a split conv of this shape adds its partials in place (ConvParams::tile_cnt given): its fused statistics
 // then have the unsplit layout, HWo / conv_tile_m() slices per image; HWo = pixels of one image (and phase)
 bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases = 1);
+// true when launch_conv can run this 3x3 / stride-1 / split-f16 conv with the producer-side GroupNorm of its output
+// (ConvParams::gnf_*): p as it will be launched, without the gnf fields
+bool conv_gnf_supported(const ConvParams &p, int groups);
+constexpr int CONV_GNF_COUNTERS = 8192;     // capacity of ConvParams::gnf_cnt (images x N-tiles of one launch)
 constexpr int CONV_TILE_COUNTERS = 8192;    // capacity of ConvParams::tile_cnt (tiles x phases of one launch)
 // a split conv's fused GroupNorm statistics come out of its reduce pass: slices per image (and per
 // sub-pixel phase) for an output of HWo pixels; the caller sizes / strides ConvParams::stats with it
