@@ -235,7 +235,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 // 128x64 tile as much as a third of its K loop.
 // colbias[BN] (LDS, staged by the producers at kernel start so that no global load sits on the
 // epilogue's critical path): bias + FeatureWiseAffine bias when the whole tile lies in one image
-// (flag in colbias[BN]); otherwise bias only and the per-image part is gathered per row.
+// (one_img: the flag the producers leave behind the table); otherwise bias only and the per-image part is
+// gathered per row. BN may be a column slice of the block's tile (in-place split-K: n0 and colbias advanced by it).
 // QRED (persistent kernel): the four row groups of a wave are added by lane exchange first, only lanes q == 0
 // write [wm][column] entries (a quarter of the staging space) and the caller does the barrier
 // GNF (producer-side GroupNorm of the output, ConvParams::gnf_*): the column statistics go out FIRST (phase 6 moves in
@@ -244,11 +245,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x16 (&acc)
 template <int BM, int BN, int WGM, int WGN, int MT, int NT, bool QRED = false, bool GNF = false>
 __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc)[MT][NT], float *smem,
                                                 const int *rowpix, const int *rowimg, int m0, int n0, int M, int wm,
-                                                int wn, int l16, int q, const float *colbias) {
+                                                int wn, int l16, int q, const float *colbias, const bool one_img) {
     constexpr int WM = BM / WGM, WN = BN / WGN;
     static_assert(!(GNF && QRED), "the persistent experiment has no producer-side GroupNorm");
     const unsigned Cout = (unsigned)p.out.C;
-    const bool one_img = reinterpret_cast<const int *>(colbias)[BN] != 0;
     const unsigned ncol = (unsigned)(n0 + wn * WN + l16);       // column of nt = 0; + 16 per nt
     // element offset of (row, column 0) for this lane's 4 rows of every row tile
     unsigned rb[MT][4];
@@ -968,6 +968,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     const int HWo = p.Hout * W;
     const int M = p.B * HWo;
     const int tilesN = (Cout + BN - 1) / BN;
+    const int nsplit = (!GNF && MS == 16 && p.splits > 1) ? p.splits : 1;     // in-place split-K (end of the consumer path)
     int bid = blockIdx.x;
     if (GNF) {
         // Block order of the producer-side GroupNorm: the blocks of one image must be dispatched together (they wait
@@ -989,19 +990,34 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             if (image >= p.B) return;
             bid = image * per + (loc % per);
         }
+    } else if (nsplit > 1) {
+        // split-K: the grid is (tiles padded to a multiple of 8) x splits in ONE dimension; XCD x = blockIdx.x & 7 takes
+        // tiles [x * tpx, (x + 1) * tpx), the splits of a tile adjacent in its dispatch sequence — the blocks that wait
+        // for each other at the end of the kernel are always dispatched together, whatever the tile count
+        const int xcd = bid & 7, loc = bid >> 3;
+        const int tpx = (int)gridDim.x / (8 * nsplit);
+        bid = (xcd * tpx + loc / nsplit) * nsplit + loc % nsplit;
+        if (bid / nsplit >= (M / BM) * tilesN) return;          // padding
     } else {
         const int nwg = gridDim.x;
         const int xcd = bid & 7, loc = bid >> 3;
         const int qq = nwg >> 3, rr = nwg & 7;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
     }
+    const int split = bid % nsplit;
+    bid /= nsplit;
     const int m0 = (bid / tilesN) * BM;
     const int n0 = (bid % tilesN) * BN;
     const int SEG = min(W, BM), SEGP = SEG + HALO, nseg = BM / SEG;
     const int rows_a = nseg * SEGP;
-    const int nkh = TAPS * (Cin / BK);                 // halo-phase K-steps
     const int C2a = p.in2.p ? p.in2.C : 0, C2 = C2a + (p.in2b.p ? p.in2b.C : 0);
-    const int nk = nkh + C2 / BK;
+    // split-K (in place, see the end of the kernel): this block reduces the input-channel chunks
+    // [cb, ce) (all taps) and the chunks [c2b, c2e) of the fused 1x1 term — both divided, like the generic kernel
+    const int nchunk = Cin / BK, nchunk2 = C2 / BK;
+    const int cb = (int)((long)nchunk * split / nsplit) * BK, ce = (int)((long)nchunk * (split + 1) / nsplit) * BK;
+    const int c2b = (int)((long)nchunk2 * split / nsplit) * BK, c2e = (int)((long)nchunk2 * (split + 1) / nsplit) * BK;
+    const int nkh = TAPS * ((ce - cb) / BK);           // halo-phase K-steps
+    const int nk = nkh + (c2e - c2b) / BK;
     const int G = nkh / KS;                             // A groups of the halo phase
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1098,8 +1114,8 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         int nh = 0;                                     // halo DMA instructions of this wave per group
         static_for<ARH>([&](auto ic) { if ((4 * decltype(ic)::value + w) * 8 < rows_a) ++nh; });
         int k = 0;
-        SR3_ISSUE_HALO(0, 0)
-        for (int c0 = 0; c0 < Cin; c0 += BK) {
+        if (cb < ce) SR3_ISSUE_HALO(cb, 0)
+        for (int c0 = cb; c0 < ce; c0 += BK) {
             const char *wbase = reinterpret_cast<const char *>(p.w + c0);
             static_for<TAPS>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
@@ -1121,7 +1137,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                     if (dy < KS - 1) {
                         SR3_ISSUE_HALO(c0, dy + 1)
                         halo_now = true;
-                    } else if (c0 + BK < Cin) {
+                    } else if (c0 + BK < ce) {
                         SR3_ISSUE_HALO(c0 + BK, 0)
                         halo_now = true;
                     }
@@ -1160,7 +1176,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         }
 #undef SR3_ISSUE_HALO
         // fused 1x1 term: plain BM-row A tiles continue in the A ring
-        for (int c0 = 0; c0 < C2; c0 += BK) {
+        for (int c0 = c2b; c0 < c2e; c0 += BK) {
             float *Ad = Aring + (ga & 1) * ASTG + w * 256;
             float *Bd = Bring + (k & 1) * BSTG + w * 256;
             const bool first2 = c0 < C2a;
@@ -1190,7 +1206,8 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             gnf_producer_tail<BM, BN, WGM * 4>(p, smem, m0, n0, HWo, tid);
             return;
         }
-        if (p.stats != nullptr) producer_stats_tail<BM, BN, WGM, MS == 16 ? 4 : 2>(p, smem, m0, n0, HWo);
+        // (in-place split-K: the consumer waves of the tile's last block write the statistics themselves)
+        if (p.stats != nullptr && nsplit == 1) producer_stats_tail<BM, BN, WGM, MS == 16 ? 4 : 2>(p, smem, m0, n0, HWo);
         return;
     }
 
@@ -1396,13 +1413,121 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
 #undef SR3_AADDR
 #undef SR3_BREAD
 #undef SR3_MMA16
+        if constexpr (!GNF) {
+        if (nsplit > 1) {
+            // In-place split-K as a reduce-scatter (launch_conv: deep-K convs over few 128x128 tiles — the 8x8 level at
+            // B = 64). Every block leaves its raw partial sums in part[tile][split] in the wave's own register order
+            // (1 KiB per wave instruction), counts itself on the tile's counter and waits until all nsplit blocks of the
+            // tile have (they are adjacent in the grid: dispatched together; the poll is bounded all the same). Then
+            // block `split` adds COLUMN SLICE `split` of all partials in split order — bit-identical whatever the
+            // arrival order — and runs the epilogue and the statistics for those BN / nsplit columns: the tail of a
+            // tile is shared by its blocks instead of falling on the last one. Hand-off form as in the 64x64 kernel:
+            // sc1 stores, s_waitcnt vmcnt(0) in every storing wave, barrier, one agent-scope add; sc1 loads.
+            // The producer waves have retired (a barrier counts live waves only).
+            const size_t tstride = (size_t)4 * MT * NT * 256;                     // floats of one partial tile image
+            float *pbase = p.part + (size_t)bid * nsplit * tstride + ((size_t)wid * MT * NT * 64 + lane) * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(pbase + (size_t)split * tstride + (size_t)(mt * NT + nt) * 256);
+                    const unsigned long long lo2 = (unsigned long long)__float_as_uint(acc[mt][nt][0]) | ((unsigned long long)__float_as_uint(acc[mt][nt][1]) << 32);
+                    const unsigned long long hi2 = (unsigned long long)__float_as_uint(acc[mt][nt][2]) | ((unsigned long long)__float_as_uint(acc[mt][nt][3]) << 32);
+                    __hip_atomic_store(dst, lo2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, hi2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the partials have reached the coherence point ...
+            __syncthreads();                                        // ... in all four consumer waves
+            unsigned *cnt = p.tile_cnt + (size_t)bid;
+            if (threadIdx.x == 0) {
+                const unsigned arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived + 1u < (unsigned)nsplit) {
+                    const long long t0 = __builtin_amdgcn_s_memtime();
+                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsplit) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {        // ~2.7 s: never in a healthy run
+                            if (p.ovf != nullptr) atomicOr(p.ovf, SR3_FLAG_GNF_TIMEOUT);
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const float *colb = colbias;
+            const bool one_img = reinterpret_cast<const int *>(colbias)[BN] != 0;
+            auto slice = [&](auto ntq_c) {
+                constexpr int NTQ = decltype(ntq_c)::value;             // column tiles of this block's slice
+                f32x4 aq[MT][NTQ];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int u = 0; u < NTQ; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) aq[mt][u][r] = 0.f;
+                for (int sp = 0; sp < nsplit; ++sp) {
+                    unsigned long long t[MT][NTQ][2];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int u = 0; u < NTQ; ++u) {
+                            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
+                                pbase + (size_t)sp * tstride + (size_t)(mt * NT + split * NTQ + u) * 256);
+                            t[mt][u][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            t[mt][u][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int u = 0; u < NTQ; ++u) {
+                            aq[mt][u][0] += __uint_as_float((unsigned)t[mt][u][0]);
+                            aq[mt][u][1] += __uint_as_float((unsigned)(t[mt][u][0] >> 32));
+                            aq[mt][u][2] += __uint_as_float((unsigned)t[mt][u][1]);
+                            aq[mt][u][3] += __uint_as_float((unsigned)(t[mt][u][1] >> 32));
+                        }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int u = 0; u < NTQ; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) aq[mt][u][r] *= p.w_unscale;
+                constexpr int BNQ = 16 * NTQ;
+                const int n0q = n0 + split * BNQ;
+                conv_epilogue16<BM, BNQ, WGM, 1, MT, NTQ>(p, aq, smem, rowpix, rowimg, m0, n0q, M, wm, 0, l16, q, colb + split * BNQ, one_img);
+                if (p.stats != nullptr) {
+                    // (the epilogue ended with a barrier behind the staged column sums.) A tile may cover several whole
+                    // images (8x8 level: HWo = 64 < BM): the row groups of image i of the tile are entries
+                    // [i * per, (i + 1) * per) of the WGM * 4 staged ones, one slice per image; else one slice per tile
+                    const double2 *red = reinterpret_cast<const double2 *>(smem);
+                    const int imgs = HWo < BM ? BM / HWo : 1, per = (WGM * 4) / imgs;
+                    for (int e = threadIdx.x; e < imgs * BNQ; e += 256) {
+                        const int im = e / BNQ, col = e - im * BNQ;
+                        double a = 0, b = 0;
+                        for (int j = 0; j < per; ++j) { const double2 t2 = red[(im * per + j) * BNQ + col]; a += t2.x; b += t2.y; }
+                        const int m_img = m0 + im * (BM / imgs);
+                        const int n = m_img / HWo, slc = p.stats_slice0 + (m_img - n * HWo) / BM;
+                        double *o = p.stats + (((size_t)n * p.stats_slices + slc) * Cout + n0q + col) * 2;
+                        o[0] = a; o[1] = b;
+                    }
+                }
+            };
+            if (nsplit == 2) slice(std::integral_constant<int, NT / 2>{});
+            else slice(std::integral_constant<int, (NT / 4 > 0 ? NT / 4 : 1)>{});
+            if (threadIdx.x == 0) {                 // departed; the last one leaves the counter at zero for the next launch
+                const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == 2u * (unsigned)nsplit - 1u) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] *= p.w_unscale;
-        conv_epilogue16<BM, BN, WGM, WGN, MT, NT, false, GNF>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, l16, q, colbias);
+        conv_epilogue16<BM, BN, WGM, WGN, MT, NT, false, GNF>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, l16, q, colbias,
+                                                              reinterpret_cast<const int *>(colbias)[BN] != 0);
         return;
     }
     const int li = lane & 31, lh = lane >> 5;
@@ -1854,7 +1979,8 @@ __global__ __launch_bounds__(512, (BN == 64) ? 6 : 4) void conv3x3_halo_pt(const
         // instead of being carried through the K loop)
         int l16e = l16, qe = q;
         asm volatile("" : "+v"(l16e), "+v"(qe));
-        conv_epilogue16<BM, BN, WGM, WGN, MT, NT, true>(pl, acc, stat_stage, rowpix, rowimg, m0, n0, M, wm, wn, l16e, qe, colbias);
+        conv_epilogue16<BM, BN, WGM, WGN, MT, NT, true>(pl, acc, stat_stage, rowpix, rowimg, m0, n0, M, wm, wn, l16e, qe, colbias,
+                                                        reinterpret_cast<const int *>(colbias)[BN] != 0);
         if (has_stats) __syncthreads();             // E: column sums staged for the producer threads
     }
 }
@@ -1903,6 +2029,7 @@ void launch_halo(const ConvParams &p, hipStream_t s) {
     const int M = p.B * p.Hout * p.Wout;
     int grid = (M / BM) * ((p.out.C + BN - 1) / BN);
     if (GNF && p.gnf_band == 0) grid = (p.B + 7) / 8 * 8 * ((p.Hout * p.Wout) / BM) * (p.out.C / BN);   // whole rounds of eight images
+    if (!GNF && MS == 16 && p.splits > 1) grid = (grid + 7) / 8 * 8 * p.splits;     // in-place split-K: see the kernel's block order
     hipLaunchKernelGGL(kern, dim3(grid, 1, p.phases), dim3(512), lds, s, p);
 }
 
@@ -1923,9 +2050,9 @@ static bool halo_persistent() {
 #endif
 
 // preconditions of the x-halo kernel for tile height BM
-static bool halo_ok(const ConvParams &p, int BM, int segmin, int bn) {
+static bool halo_ok(const ConvParams &p, int BM, int segmin, int bn, bool split_ok = false) {
     static const int off = getenv("SR3_NO_HALO") ? atoi(getenv("SR3_NO_HALO")) : 0;
-    if (off || p.prec != 1 || (p.ks != 3 && p.ks != 2) || p.stride != 1 || p.up2 || p.splits > 1 || p.in0.pad != 1) return false;
+    if (off || p.prec != 1 || (p.ks != 3 && p.ks != 2) || p.stride != 1 || p.up2 || (p.splits > 1 && !split_ok) || p.in0.pad != 1) return false;
     const int W = p.Wout;
     if (p.in0.W != W || p.in0.H != p.Hout) return false;
     const int seg = W < BM ? W : BM;
@@ -2101,6 +2228,30 @@ int conv_splits(long M, int Cout, int Cin) {
     return s;
 }
 
+// Deep-K 3x3 / stride-1 split-f16 convs over FEW output tiles (the 8x8 level at B = 64: M = 4096 pixels, 512 channels):
+// instead of 64x64 tiles of the generic kernel (LDS traffic per MFMA twice that of a 128x128 tile) they run on the
+// 128x128 x-halo tile with the K range split over `return value` blocks per tile, added IN PLACE by the block that
+// arrives last (conv3x3_halo_h3, end of the consumer path) — no reduce pass, statistics in the unsplit layout (one
+// slice per 128-row tile, or one per image where a tile covers several whole images). 0 or 1: not for this shape.
+// Assumes ks 3, stride 1, prec 1, pad 1 (launch_conv checks them); sr3_api.hip sizes the partial buffer with it.
+int conv_halo_splits(long M, int H, int W, int Cout, int Cin) {
+    static const int force = getenv("SR3_HALO_SPLITS") ? atoi(getenv("SR3_HALO_SPLITS")) : -1;    // A/B: 0 off, N forced
+    if (force == 0 || !halo_mfma16()) return 0;
+    const int HWo = H * W;
+    if (W < 8 || (M % 128) || (Cout % 128) || (Cin % 32)) return 0;
+    const int seg = W < 128 ? W : 128;
+    if ((W % seg) || (128 % seg)) return 0;
+    if (HWo >= 128 ? (HWo % 128) != 0 : ((128 % HWo) != 0 || (HWo % 32) != 0)) return 0;
+    if (conv_tile_choice(M, Cout) != 2) return 0;                  // enough 128-row tiles already: no split needed
+    const long tiles = (M / 128) * (Cout / 128);
+    const int nchunk = Cin / 32;
+    if (tiles < 64 || tiles > CONV_TILE_COUNTERS || nchunk < 8) return 0;
+    int sp = 2;
+    while (sp * 2 <= nchunk / 4 && tiles * sp * 2 <= 512 && sp < 4) sp *= 2;      // (the reduce-scatter tail handles 2 or 4 splits)
+    if (force == 2 || force == 4) sp = force;
+    return sp;
+}
+
 bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases) {
     static const int off = getenv("SR3_NO_INPLACE_SPLIT") ? atoi(getenv("SR3_NO_INPLACE_SPLIT")) : 0;
     if (off || conv_splits(M, Cout, Cin) <= 1) return false;
@@ -2173,6 +2324,18 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         p.w_shift = lg(p.Wout);
     }
     if (p.part == nullptr) p.splits = 1;
+    if (p.prec == 1 && p.ks == 3 && p.stride == 1 && !p.up2 && p.phases == 1 && p.part != nullptr && p.tile_cnt != nullptr &&
+        p.in0.pad == 1 && p.in0.W == p.Wout && p.in0.H == p.Hout && p.gnf_gamma == nullptr) {
+        const int hs = conv_halo_splits(M, p.Hout, p.Wout, p.out.C, p.in0.C + (p.in1.p ? p.in1.C : 0));
+        const int HWo = p.Hout * p.Wout;
+        const bool stats_ok = p.stats == nullptr || p.stats_slices == (HWo >= 128 ? HWo / 128 : 1);
+        if (hs > 1 && stats_ok) {
+            p.splits = hs;
+            if (halo_ok(p, 128, 32, 128, true)) { launch_halo<128, 128, 4, 1, 32, 3, 16>(p, s); return; }
+            if (halo_ok(p, 128, 8, 128, true)) { launch_halo<128, 128, 4, 1, 8, 3, 16>(p, s); return; }
+            p.splits = p_in.splits;
+        }
+    }
     const bool inplace = p.splits > 1 && p.tile_cnt != nullptr &&
                          conv_split_inplace(M, p.Hout * p.Wout, p.out.C, p.in0.C + (p.in1.p ? p.in1.C : 0), p.phases);
     if (!inplace) p.tile_cnt = nullptr;

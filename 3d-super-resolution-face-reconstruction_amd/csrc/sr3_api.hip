@@ -493,7 +493,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
         {   // split-K partial buffer: largest splits * M * Cout over the convs of this module
             const long Mo = (long)B * h * w;
             auto want = [&](int cout, int cin) {
-                const int sp = conv_splits(Mo, cout, cin);
+                const int sp = std::max(conv_splits(Mo, cout, cin), conv_halo_splits(Mo, h, w, cout, cin));
                 if (sp > 1) max_part = std::max<uint64_t>(max_part, (uint64_t)sp * Mo * cout);
             };
             if (m.kind == M_RES) {
@@ -966,8 +966,8 @@ int range_read(sr3_ctx *c) {
     const int v = *c->h_ovf;
     HIP_OK(hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream));
     if (v & SR3_FLAG_GNF_TIMEOUT)
-        return fail("internal: a producer-side GroupNorm wait timed out (the blocks of an image were not dispatched "
-                    "together); the result is invalid — set SR3_NO_GNF=1 to use the separate apply pass and report this");
+        return fail("internal: blocks of one conv tile that wait for each other (in-place split-K) were not dispatched "
+                    "together and the bounded wait gave up; the result is invalid — set SR3_HALO_SPLITS=0 and report this");
     return 1;
 }
 
@@ -1565,8 +1565,9 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     {
         const long Mo = (long)B * (up2 ? Hin * Win : p.Hout * p.Wout);
         p.splits = conv_splits(Mo, Cout, Cin);
-        if (p.splits > 1) {
-            HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * p.splits * Mo * Cout * sizeof(float)));
+        const int hs = (c->prec && ks == 3 && stride == 1 && !up2) ? conv_halo_splits(Mo, p.Hout, p.Wout, Cout, Cin) : 0;
+        if (p.splits > 1 || hs > 1) {
+            HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * std::max(p.splits, hs) * Mo * Cout * sizeof(float)));
             p.part = part;
             p.tile_cnt = c->tile_cnt;
         }
@@ -1624,8 +1625,9 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     {
         const long Mo = (long)B * (up2 ? (Ho / 2) * (Wo / 2) : Ho * Wo);
         p.splits = conv_splits(Mo, Cout, Cin);
-        if (p.splits > 1) {
-            HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * p.splits * Mo * Cout * sizeof(float)));
+        const int hs = (c->prec && ks == 3 && stride == 1 && !up2) ? conv_halo_splits(Mo, Ho, Wo, Cout, Cin) : 0;
+        if (p.splits > 1 || hs > 1) {
+            HIP_OK(hipMalloc(&part, (size_t)(up2 ? 4 : 1) * std::max(p.splits, hs) * Mo * Cout * sizeof(float)));
             p.part = part;
             p.tile_cnt = c->tile_cnt;
         }

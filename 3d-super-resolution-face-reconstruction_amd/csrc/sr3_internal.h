@@ -102,7 +102,8 @@ struct ConvParams {
     int gnf_band = 0;                  // > 0: M-tiles of an image per XCD (band block order, set by launch_conv)
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
-// value written to *ConvParams::ovf when a producer-side GroupNorm wait gives up (the dispatch-order assumption failed)
+// bit raised in *ConvParams::ovf when a bounded inter-block wait gives up (in-place split-K of the x-halo kernel; the
+// producer-side GroupNorm experiment): the API call then fails
 constexpr int SR3_FLAG_GNF_TIMEOUT = 2;
 // largest magnitude the split-f16 format (hi + lo, both fp16) can hold
 constexpr float SPLIT_F16_MAX = 65504.0f;
@@ -147,6 +148,8 @@ bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases = 1);
 // (ConvParams::gnf_*): p as it will be launched, without the gnf fields
 bool conv_gnf_supported(const ConvParams &p, int groups);
 constexpr int CONV_GNF_COUNTERS = 8192;     // capacity of ConvParams::gnf_cnt (images x N-tiles of one launch)
+// K-splits of the 128x128 x-halo tile for deep-K 3x3 / stride-1 split-f16 convs over few tiles (kernels_conv.hip); <= 1: none
+int conv_halo_splits(long M, int H, int W, int Cout, int Cin);
 constexpr int CONV_TILE_COUNTERS = 8192;    // capacity of ConvParams::tile_cnt (tiles x phases of one launch)
 // a split conv's fused GroupNorm statistics come out of its reduce pass: slices per image (and per
 // sub-pixel phase) for an output of HWo pixels; the caller sizes / strides ConvParams::stats with it

@@ -43,6 +43,11 @@ CONV_CASES = [
     (64, 32, 32, 128, 0, 128, 3, 1, False),   # 128x128 halo tile
     (64, 8, 8, 512, 0, 512, 3, 1, False),     # small M, deep K (the 8x8 level): 64x64 tile, 4-stage ring
     (64, 16, 16, 256, 0, 256, 3, 2, False),   # Downsample at full batch
+    # few 128x128 tiles, deep K: x-halo tile with in-place split-K (f16x3; conv_halo_splits)
+    (64, 8, 8, 512, 512, 512, 3, 1, False),   # tiles cover two whole images each, concatenated input
+    (32, 8, 8, 512, 0, 512, 3, 1, False),     # 64 tiles
+    (36, 8, 8, 512, 0, 512, 3, 1, False),     # 72 tiles: not a multiple of 8 (padded block order)
+    (16, 16, 16, 512, 0, 256, 3, 1, False),   # two tiles per image, two N-tiles
     # split-K shapes (few tiles, deep K: small batches)
     (1, 8, 8, 512, 0, 512, 3, 1, False),      # one M-tile, 8 N-tiles: in-place split-K (whole tiles per image)
     (1, 16, 16, 256, 256, 256, 3, 1, False),  # in place, concatenated input, 4 M-tiles
