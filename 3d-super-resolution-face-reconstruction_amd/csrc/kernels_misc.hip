@@ -665,6 +665,15 @@ namespace {
 
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+// compile-time loop (every index a constant in the front end)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 // Operand ring of two register sets over n steps: the fragments of step i + 1 are in flight while step i multiplies
 // (steps past the end re-fetch the last one: unused). fetch(set, step), mult(set, step). Four sets were tried in the
 // 64-query form (240 registers): 0.487 against 0.473 ms per step (profiles/README.md finding 43).
@@ -679,6 +688,23 @@ __device__ __forceinline__ void attn_ring2(int n, FE &&fetch, MU &&mult) {
             mult(std::integral_constant<int, 1>{}, c + 1);
         }
     }
+}
+
+// The same ring with a compile-time step count, fully unrolled, NS register sets deep (NS - 1 steps in flight): without
+// a loop back-edge the compiler counts the outstanding loads exactly (`s_waitcnt vmcnt(N)` with N = the loads of the
+// younger steps) — in the rolled loop it drained `vmcnt(0)` at the top of every iteration, so one step of MFMAs was all
+// that ever covered a load's latency (the block is alone on its CU: nobody else hides it).
+template <int N, int NS, typename FE, typename MU>
+__device__ __forceinline__ void attn_ring_static(FE &&fetch, MU &&mult) {
+    static_for<(NS - 1 < N ? NS - 1 : N)>([&](auto ic) { fetch(std::integral_constant<int, decltype(ic)::value % NS>{}, decltype(ic)::value); });
+    __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks the loads next to their uses: nothing in flight)
+    static_for<N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i + NS - 1 < N) fetch(std::integral_constant<int, (i + NS - 1) % NS>{}, i + NS - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(std::integral_constant<int, i % NS>{}, i);
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 // v^T in the split format: vt[b][c][Np / 32 chunks][32 hi halfs of keys | 32 lo halfs] from the token-major
@@ -724,7 +750,9 @@ __global__ __launch_bounds__(256) void attention_vt_kernel(const float *__restri
 // NTW / NTC: key tiles (scores) and channel tiles (P v) per wave, compile-time maxima; MTQ: 16-query tiles per block
 // (32 or 64 queries); NWAVES: waves per block. 64 queries x 8 waves halves the k / v^T bytes a block pulls through
 // L2 per query (the kernel is bound by that traffic) at the same number of waves per CU.
-template <int NTW, int NTC, int MTQ, int NWAVES>
+// NCH / NKS > 0: channel chunks (C / 32) and key steps (Np / 32) known at compile time — both operand loops fully unrolled
+// over deeper register rings (attn_ring_static); 0: run-time counts, two-set rings.
+template <int NTW, int NTC, int MTQ, int NWAVES, int NCH = 0, int NKS = 0>
 __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const float *__restrict__ qkv, const float *__restrict__ vt,
                                                               int N, int C, float *__restrict__ out,
                                                               float *__restrict__ out_split, int *ovf, int dbg) {
@@ -757,7 +785,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
     // 4 C + 32 bytes: the 16-byte fragment reads of a lane group fall on distinct banks. The score tile S takes
     // over the same LDS region once the scores are in registers. ----
     constexpr bool QLDS = MTQ == 4;
-    constexpr int NSET = 2;     // register sets of the operand rings
+    constexpr bool STATIC = NCH > 0 && NKS > 0;
+    constexpr int NSET = STATIC ? 4 : 2;     // register sets of the k ring (scores)
+    constexpr int NSETV = STATIC ? 3 : 2;    // register sets of the v^T ring (P v)
+    constexpr int NSETQ = 2;                 // q fragments (LDS or global): one step ahead
     const int qstride = C * 4 + 32;
     if (QLDS) {
         char *Q = reinterpret_cast<char *>(S);
@@ -805,7 +836,37 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
         if (wid * NTW < nkt && !(dbg & 1)) {
             // the fragments of chunk ch + 1 are in flight while chunk ch multiplies (two register sets; rows of
             // tiles past the end are clamped duplicates whose scores are never stored)
-            h16x8 ah[NSET][MTQ], al[NSET][MTQ], bh[NSET][NTW], bl[NSET][NTW];
+            if constexpr (STATIC) {
+                // k fragments (global memory) NSET - 1 chunks ahead, q fragments (LDS) read in the step that uses them
+                h16x8 bh[NSET][NTW], bl[NSET][NTW];
+                auto fetch = [&](auto setc, int ch) {
+                    constexpr int set = decltype(setc)::value;
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) {
+                        bh[set][i] = *reinterpret_cast<const h16x8 *>(krow[i] + ch * 128);
+                        bl[set][i] = *reinterpret_cast<const h16x8 *>(krow[i] + ch * 128 + 64);
+                    }
+                };
+                auto mult = [&](auto setc, int ch) {
+                    constexpr int set = decltype(setc)::value;
+                    h16x8 ah[MTQ], al[MTQ];
+#pragma unroll
+                    for (int mt = 0; mt < MTQ; ++mt) {
+                        ah[mt] = *reinterpret_cast<const h16x8 *>(qrow[mt] + ch * 128);
+                        al[mt] = *reinterpret_cast<const h16x8 *>(qrow[mt] + ch * 128 + 64);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MTQ; ++mt) {
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[set][i], acc[i][mt], 0, 0, 0);
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl[set][i], acc[i][mt], 0, 0, 0);
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[set][i], acc[i][mt], 0, 0, 0);
+                        }
+                };
+                attn_ring_static<NCH, NSET>(fetch, mult);
+            } else {
+            h16x8 ah[NSETQ][MTQ], al[NSETQ][MTQ], bh[NSETQ][NTW], bl[NSETQ][NTW];
             auto fetch = [&](auto setc, int ch) {
                 constexpr int set = decltype(setc)::value;
 #pragma unroll
@@ -831,6 +892,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                     }
             };
             attn_ring2(nch, fetch, mult);
+            }
         }
         if (QLDS) __syncthreads();          // every wave has read its last q fragment: S may overwrite the q rows
         // C/D map: col = l16 (key), row = 4 q4 + j (query)
@@ -917,7 +979,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
     {
         // v^T fragments of key step ks + 1 in flight while step ks multiplies (channel tiles past the end are
         // clamped duplicates that are never stored)
-        h16x8 vh[NSET][NTC], vl[NSET][NTC];
+        h16x8 vh[NSETV][NTC], vl[NSETV][NTC];
         auto fetch = [&](auto setc, int ks) {
             constexpr int set = decltype(setc)::value;
 #pragma unroll
@@ -944,7 +1006,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_split_kernel(const floa
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], vh[set][t], acc[t][mt], 0, 0, 0);
                 }
         };
-        if (!(dbg & 4)) attn_ring2(nks, fetch, mult);
+        if constexpr (STATIC) attn_ring_static<NKS, NSETV>(fetch, mult);
+        else if (!(dbg & 4)) attn_ring2(nks, fetch, mult);
     }
     // C/D map: col = l16 (channel), row = 4 q4 + j (query)
 #pragma unroll
@@ -992,21 +1055,23 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
 #ifdef SR3_EXPERIMENTS
     if (const char *e = getenv("SR3_ATTN_DBG")) dbg = atoi(e);
 #endif
-#define SR3_AT(A, B_, MQ, W_)                                                                                      \
+#define SR3_AT(A, B_, MQ, W_, CH_, KS_)                                                                            \
     {                                                                                                              \
         static size_t attr = 0;                                                                                    \
         if (lds > attr) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<A, B_, MQ, W_>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<A, B_, MQ, W_, CH_, KS_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
             attr = lds;                                                                                            \
         }                                                                                                          \
-        hipLaunchKernelGGL((attention_split_kernel<A, B_, MQ, W_>), dim3((Np / QB) * B), dim3(W_ * 64), lds, s, qkv_split, vt, \
-                           N, C, out, out_split, ovf, dbg);                                                        \
+        hipLaunchKernelGGL((attention_split_kernel<A, B_, MQ, W_, CH_, KS_>), dim3((Np / QB) * B), dim3(W_ * 64), lds, s, \
+                           qkv_split, vt, N, C, out, out_split, ovf, dbg);                                         \
     }
-    if (big) SR3_AT(2, 4, 4, 8)       // (at most 256 tokens: 2 key tiles per wave; 240 registers with the 4-set rings)
-    else if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2, 2, 4)
-    else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8, 2, 4)
-    else SR3_AT(8, 8, 2, 4)
+    static const int attn_static = getenv("SR3_ATTN_STATIC") ? atoi(getenv("SR3_ATTN_STATIC")) : 1;    // A/B: rolled two-set rings
+    if (big && attn_static && C == 512 && Np == 256 && dbg == 0) SR3_AT(2, 4, 4, 8, 16, 8)     // config 3: unrolled, deep rings
+    else if (big) SR3_AT(2, 4, 4, 8, 0, 0)       // (at most 256 tokens: 2 key tiles per wave)
+    else if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2, 2, 4, 0, 0)
+    else if (ntw <= 4 && ntc <= 8) SR3_AT(4, 8, 2, 4, 0, 0)
+    else SR3_AT(8, 8, 2, 4, 0, 0)
 #undef SR3_AT
     return 4.0 * (double)B * N * N * C;
 }
