@@ -154,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
         return;
     }
     // processed 4 accumulator registers (4 consecutive rows) at a time to keep registers low
-    float split_absmax = 0.f;          // largest |value| stored in the split-f16 format (range check)
+    unsigned split_range = 0;          // running max of the stored hi halfs' exponent fields (range check; catches NaN too)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * WN + ni * 32 + li;
@@ -194,8 +194,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
                         // no clamp: a value beyond the fp16 range is DETECTED (split_absmax -> ConvParams::ovf,
                         // the API call then fails) instead of being silently saturated
                         const float g = v;
-                        split_absmax = fmaxf(split_absmax, fabsf(g));
                         const _Float16 hi = (_Float16)g;
+                        {
+                            const unsigned eb = (unsigned)__builtin_bit_cast(unsigned short, hi) & 0x7C00u;
+                            split_range = eb > split_range ? eb : split_range;
+                        }
                         const _Float16 lo = (_Float16)(g - (float)hi);
                         const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) |
                                              ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
@@ -215,7 +218,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvParams &p, f32x16 (
         if (p.stats != nullptr)
             reinterpret_cast<double2 *>(smem)[(wm * 2 + lh) * BN + wn * WN + ni * 32 + li] = make_double2(st1, st2);
     }
-    if (p.ovf != nullptr && split_absmax > SPLIT_F16_MAX) *p.ovf = 1;
+    if (p.ovf != nullptr && split_range_overflow(split_range)) *p.ovf = 1;
     if (p.stats != nullptr) __syncthreads();
 }
 

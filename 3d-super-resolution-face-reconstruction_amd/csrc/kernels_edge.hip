@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void final_conv_mfma_kernel(const TDesc x, con
                                                               const float *__restrict__ shift,
                                                               const h16x8 *__restrict__ wfr,   // [kstep][nt 2][hi|lo][lane 64]
                                                               const float w_unscale, const float *__restrict__ bias,
-                                                              const TDesc out) {
+                                                              const TDesc out, int *ovf) {
     constexpr int HR = 10, HC = 34, NPIX = HR * HC, MTILES = (NPIX + 15) / 16, YLD = 33;
+    unsigned range_bits = 0;        // running max of the hi halfs' exponent fields: 0x7C00 = beyond hi + lo, or not finite
     __shared__ float Y[MTILES * 16 * YLD];
     const int C = x.C, H = x.H, W = x.W, Cout = out.C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(256) void final_conv_mfma_kernel(const TDesc x, con
                 a = ok ? a : 0.f;
                 ah[e] = (_Float16)a;
                 al[e] = (_Float16)(a - (float)ah[e]);
+                const unsigned eb = (unsigned)__builtin_bit_cast(unsigned short, ah[e]) & 0x7C00u;
+                range_bits = eb > range_bits ? eb : range_bits;
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(256) void final_conv_mfma_kernel(const TDesc x, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) Y[(mt * 16 + 4 * q + j) * YLD + nt * 16 + l16] = acc[nt][j] * w_unscale;
     }
+    if (ovf != nullptr && split_range_overflow(range_bits)) *ovf = 1;      // (the activations are split on the fly: same contract)
     __syncthreads();
     const int oy = threadIdx.x >> 5, ox = threadIdx.x & 31;
     const int yy = y0 + oy, xx = x0 + ox;
@@ -297,13 +301,13 @@ float pack_final_conv_mfma_weight(const float *oihw, int C, float *dst_as_float)
 }
 
 void launch_final_conv_mfma(const TDesc &x, int B, const float *scale, const float *shift, const float *wfr, float w_unscale,
-                            const float *bias, const TDesc &out, hipStream_t s) {
+                            const float *bias, const TDesc &out, hipStream_t s, int *ovf) {
     const dim3 grid((x.W + 31) / 32, (x.H + 7) / 8, B);
     const h16x8 *w = reinterpret_cast<const h16x8 *>(wfr);
     switch (x.C / 32) {
-    case 1: hipLaunchKernelGGL(final_conv_mfma_kernel<1>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out); break;
-    case 2: hipLaunchKernelGGL(final_conv_mfma_kernel<2>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out); break;
-    default: hipLaunchKernelGGL(final_conv_mfma_kernel<4>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out); break;
+    case 1: hipLaunchKernelGGL(final_conv_mfma_kernel<1>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out, ovf); break;
+    case 2: hipLaunchKernelGGL(final_conv_mfma_kernel<2>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out, ovf); break;
+    default: hipLaunchKernelGGL(final_conv_mfma_kernel<4>, grid, dim3(256), 0, s, x, scale, shift, w, w_unscale, bias, out, ovf); break;
     }
 }
 

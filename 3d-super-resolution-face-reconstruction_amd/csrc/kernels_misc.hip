@@ -1267,9 +1267,10 @@ __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     u.state.p[si] = v;
     if (u.packed != nullptr) {          // the first conv reads the state as packed split-f16 pixels (kernels_edge.hip)
         _Float16 *pk = reinterpret_cast<_Float16 *>(u.packed) + pix * 16 + u.xoff + c;
-        const _Float16 hi = (_Float16)v;        // |v| is bounded by the clamp of x0 and the noise: far inside fp16
-        pk[0] = hi;
+        const _Float16 hi = (_Float16)v;        // |v| is bounded by the clamp of x0 and the noise — an injected noise slab may
+        pk[0] = hi;                             // still be anything: detected like every other store of the format
         pk[8] = (_Float16)(v - (float)hi);
+        if (u.ovf != nullptr && ((unsigned)__builtin_bit_cast(unsigned short, hi) & 0x7C00u) == 0x7C00u) *u.ovf = 1;
     }
     if (sa.frame) sa.frame[i] = v;
 }

@@ -868,7 +868,7 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
         const bool mfma = c->prec && c->final_wm && !final_valu;
         if (mfma)
             launch_final_conv_mfma(cur, B, c->gscale, c->gshift, c->final_wm, c->final_unscale, c->params[c->final_conv.b].dev,
-                                   c->eps, c->stream);
+                                   c->eps, c->stream, c->d_ovf);
         else
             launch_final_conv(cur, B, c->gscale, c->gshift, c->final_wq, c->params[c->final_conv.b].dev, c->eps, c->stream);
         if (c->prof) {
@@ -1018,6 +1018,7 @@ void enqueue_step(sr3_ctx *c) {
     u.xoff = c->cfg.in_channel - c->cfg.out_channel;
     u.eps = c->eps;
     u.args = c->d_step;
+    u.ovf = c->prec ? c->d_ovf : nullptr;       // (the packed copy is only read in split-f16 mode)
     c->pbegin(F_MISC);
     launch_ddpm_update(u, B, c->stream);
     c->pend();

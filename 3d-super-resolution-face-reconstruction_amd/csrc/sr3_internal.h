@@ -241,6 +241,7 @@ struct UpdateParams {
     int xoff, C;        // C = image channels (3)
     TDesc eps;          // eps.C >= C
     const StepArgs *args;
+    int *ovf = nullptr; // range check of the packed copy (ConvParams::ovf contract)
 };
 void launch_ddpm_update(const UpdateParams &p, int B, hipStream_t s);
 // x <- noise (NCHW buffer or Philox draw 0) into state channels
@@ -263,7 +264,7 @@ bool final_conv_mfma_supported(int C, int Cout);
 size_t final_conv_mfma_weight_floats(int C);
 float pack_final_conv_mfma_weight(const float *oihw, int C, float *dst_as_float);
 void launch_final_conv_mfma(const TDesc &x, int B, const float *scale, const float *shift, const float *wfr, float w_unscale,
-                            const float *bias, const TDesc &out, hipStream_t s);
+                            const float *bias, const TDesc &out, hipStream_t s, int *ovf = nullptr);
 // downs.0 (Conv3x3 in_channel <= 8 -> Cout) on the packed split-f16 state: xp = [B][H+2][W+2] pixels of
 // 16 halfs (8 channels hi | lo; + 16 floats of slack behind the last pixel), wci from pack_conv_in_weight
 bool conv_in_supported(int Cin, int Cout, int H, int W);

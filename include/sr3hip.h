@@ -130,9 +130,9 @@ int sr3_sample_step(sr3_ctx *ctx, int t, const float *noise_slab_dev);
 int sr3_sample_end(sr3_ctx *ctx, float *out_dev);
 /* Range check of the split-f16 arithmetic (sr3_set_precision(ctx, 1)): the reference computes in
  * fp32 (diffusion.py:164-180, unet.py:235-265) and has no such limit, so a value that does not fit
- * the hi + lo fp16 operand format (|v| > 65504) must never pass silently. The kernels that store
- * that format in the UNet body (conv epilogues and split-K reduce, GroupNorm apply, attention, state
- * packing) raise a device flag instead of clamping.
+ * the hi + lo fp16 operand format (|v| > 65504, or a NaN) must never pass silently. Every kernel that stores
+ * or builds that format (conv epilogues and split-K fix-ups, GroupNorm apply, attention, the final conv's
+ * on-the-fly split, state packing and the DDPM update's packed state) raises a device flag instead of clamping.
  *   sr3_unet_forward, sr3_sample — the calls that own their inputs — FINISH the call like the reference would:
  *     sr3_unet_forward evaluates the forward again in exact f32; sr3_sample reads the flag every
  *     T/10 steps (one stream synchronisation each), keeps a copy of the sampler state of the last

@@ -172,6 +172,28 @@ def test_overflow_late_in_the_loop_replays_from_the_last_checkpoint():
     e.close()
 
 
+def test_packed_state_overflow_from_injected_noise_is_caught():
+    """the DDPM update writes the packed split-f16 copy of x_t; an injected noise slab large enough to push
+    x_t itself beyond the fp16 range must raise the flag there (not surface as inf / NaN images): the call is finished
+    in f32 and equals the all-f32 run."""
+    cfg = synth.tiny_unet_config()
+    sd = synth.synth_state_dict(cfg, 12)
+    T = 12
+    sched = {"schedule": "linear", "n_timestep": T, "linear_start": 1e-4, "linear_end": 2e-2}
+    e = _engine(cfg, sd, "f16x3", sched)
+    cond, noise = synth.synth_cond(2, 16, 8, 4), synth.synth_noise(T, 2, 3, 16, 16, 4)
+    noise[5] *= np.float32(3e6)                      # sigma ~ 0.1: x_t ~ 1e5..1e6 after that step
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        fin = e.sample_np(cond, noise=noise)
+    assert any(issubclass(w.category, Sr3RangeWarning) for w in rec)
+    e.set_precision("f32")
+    fin32 = e.sample_np(cond, noise=noise)
+    assert np.isfinite(fin).all()
+    np.testing.assert_allclose(fin, fin32, atol=1e-4, rtol=0)
+    e.close()
+
+
 def test_facade_finishes_overflowing_calls():
     """define_G facade, default policy: super_resolution / denoise_fn / p_sample finish like the reference."""
     import torch
