@@ -940,9 +940,13 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // MS: MFMA shape of the consumers, 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16: same
 // FLOP per cycle, but the chip holds a higher clock on it under load — MI355X_MICROARCH.md, DVFS (7))
 // GNF: producer-side GroupNorm of the output (ConvParams::gnf_*; MS == 16 only)
-template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false>
+// SPK: in-place split-K instantiation (ConvParams::splits > 1; MS == 16, KS == 3). A template parameter, not a run-time
+// branch: with the split code compiled into the one kernel the register allocation of the unsplit K loop changed
+// (scratch 76 -> 430 bytes per lane) and EVERY x-halo conv ran 20 % slower (same box: 16.35 -> 19.29 ms per B = 64 step).
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false, bool SPK = false>
 __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) void conv3x3_halo_h3(const ConvParams p_in) {
     static_assert(!GNF || (MS == 16 && KS == 3), "producer-side GroupNorm: 3x3 convs on the 16x16x32 consumers");
+    static_assert(!SPK || (MS == 16 && KS == 3 && !GNF), "in-place split-K: 3x3 convs on the 16x16x32 consumers");
     const ConvParams p = phase_params(p_in, blockIdx.z);
     static_assert(WGM * WGN == 4, "4 consumer waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     const int HWo = p.Hout * W;
     const int M = p.B * HWo;
     const int tilesN = (Cout + BN - 1) / BN;
-    const int nsplit = (!GNF && MS == 16 && p.splits > 1) ? p.splits : 1;     // in-place split-K (end of the consumer path)
+    const int nsplit = SPK ? p.splits : 1;     // in-place split-K (end of the consumer path)
     int bid = blockIdx.x;
     if (GNF) {
         // Block order of the producer-side GroupNorm: the blocks of one image must be dispatched together (they wait
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             if (image >= p.B) return;
             bid = image * per + (loc % per);
         }
-    } else if (nsplit > 1) {
+    } else if (SPK) {
         // split-K: the grid is (tiles padded to a multiple of 8) x splits in ONE dimension; XCD x = blockIdx.x & 7 takes
         // tiles [x * tpx, (x + 1) * tpx), the splits of a tile adjacent in its dispatch sequence — the blocks that wait
         // for each other at the end of the kernel are always dispatched together, whatever the tile count
@@ -1017,8 +1021,8 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     // split-K (in place, see the end of the kernel): this block reduces the input-channel chunks
     // [cb, ce) (all taps) and the chunks [c2b, c2e) of the fused 1x1 term — both divided, like the generic kernel
     const int nchunk = Cin / BK, nchunk2 = C2 / BK;
-    const int cb = (int)((long)nchunk * split / nsplit) * BK, ce = (int)((long)nchunk * (split + 1) / nsplit) * BK;
-    const int c2b = (int)((long)nchunk2 * split / nsplit) * BK, c2e = (int)((long)nchunk2 * (split + 1) / nsplit) * BK;
+    const int cb = SPK ? (int)((long)nchunk * split / nsplit) * BK : 0, ce = SPK ? (int)((long)nchunk * (split + 1) / nsplit) * BK : Cin;
+    const int c2b = SPK ? (int)((long)nchunk2 * split / nsplit) * BK : 0, c2e = SPK ? (int)((long)nchunk2 * (split + 1) / nsplit) * BK : C2;
     const int nkh = TAPS * ((ce - cb) / BK);           // halo-phase K-steps
     const int nk = nkh + (c2e - c2b) / BK;
     const int G = nkh / KS;                             // A groups of the halo phase
@@ -1117,7 +1121,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         int nh = 0;                                     // halo DMA instructions of this wave per group
         static_for<ARH>([&](auto ic) { if ((4 * decltype(ic)::value + w) * 8 < rows_a) ++nh; });
         int k = 0;
-        if (cb < ce) SR3_ISSUE_HALO(cb, 0)
+        SR3_ISSUE_HALO(cb, 0)
         for (int c0 = cb; c0 < ce; c0 += BK) {
             const char *wbase = reinterpret_cast<const char *>(p.w + c0);
             static_for<TAPS>([&](auto tc) {
@@ -1416,8 +1420,8 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
 #undef SR3_AADDR
 #undef SR3_BREAD
 #undef SR3_MMA16
-        if constexpr (!GNF) {
-        if (nsplit > 1) {
+        if constexpr (SPK) {
+        {
             // In-place split-K as a reduce-scatter (launch_conv: deep-K convs over few 128x128 tiles — the 8x8 level at
             // B = 64). Every block leaves its raw partial sums in part[tile][split] in the wave's own register order
             // (1 KiB per wave instruction), counts itself on the tile's counter and waits until all nsplit blocks of the
@@ -2016,14 +2020,14 @@ void launch_halo_pt(const ConvParams &p, hipStream_t s) {
 
 #endif  // SR3_EXPERIMENTS
 
-template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false>
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false, bool SPK = false>
 void launch_halo(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr int RA = (BM + (KS - 1) * (BM / SEGMIN) + 7) / 8 * 8;
     constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM + BN + 4) * sizeof(float);
     // (the GroupNorm hand-off stages its sums, scale / shift and the fold scratch in the rings, free after the K loop)
     static_assert(!GNF || ((size_t)WGM * 4 * BN * 16 + BN * 8 + 4096 + 16 <= ((size_t)2 * RA * ROWF + 2 * BN * ROWF) * sizeof(float)), "GNF staging fits the rings");
-    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS, GNF>;
+    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS, GNF, SPK>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2032,7 +2036,7 @@ void launch_halo(const ConvParams &p, hipStream_t s) {
     const int M = p.B * p.Hout * p.Wout;
     int grid = (M / BM) * ((p.out.C + BN - 1) / BN);
     if (GNF && p.gnf_band == 0) grid = (p.B + 7) / 8 * 8 * ((p.Hout * p.Wout) / BM) * (p.out.C / BN);   // whole rounds of eight images
-    if (!GNF && MS == 16 && p.splits > 1) grid = (grid + 7) / 8 * 8 * p.splits;     // in-place split-K: see the kernel's block order
+    if (SPK) grid = (grid + 7) / 8 * 8 * p.splits;     // in-place split-K: see the kernel's block order
     hipLaunchKernelGGL(kern, dim3(grid, 1, p.phases), dim3(512), lds, s, p);
 }
 
@@ -2334,8 +2338,8 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         const bool stats_ok = p.stats == nullptr || p.stats_slices == (HWo >= 128 ? HWo / 128 : 1);
         if (hs > 1 && stats_ok) {
             p.splits = hs;
-            if (halo_ok(p, 128, 32, 128, true)) { launch_halo<128, 128, 4, 1, 32, 3, 16>(p, s); return; }
-            if (halo_ok(p, 128, 8, 128, true)) { launch_halo<128, 128, 4, 1, 8, 3, 16>(p, s); return; }
+            if (halo_ok(p, 128, 32, 128, true)) { launch_halo<128, 128, 4, 1, 32, 3, 16, false, true>(p, s); return; }
+            if (halo_ok(p, 128, 8, 128, true)) { launch_halo<128, 128, 4, 1, 8, 3, 16, false, true>(p, s); return; }
             p.splits = p_in.splits;
         }
     }

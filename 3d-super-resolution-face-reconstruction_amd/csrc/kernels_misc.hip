@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
+#include <algorithm>
 
 namespace sr3 {
 
@@ -147,6 +148,61 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double *__restri
     }
 }
 
+// The same finalize for FEW images with MANY slices (small batches: a 128x128 image on 64x64 tiles leaves 256 slices,
+// and the folded apply's prologue — or the kernel above on B x 4 blocks — walks them in 12-16 dependent round trips).
+// One block per (image, group): its Cg x slices partial sums are all in flight at once (thread = (channel of the group,
+// slice lane)), added per channel in slice order, then per group in channel order.
+__global__ __launch_bounds__(256) void gn_finalize_group_kernel(const double *__restrict__ part0, int C0, int slices0,
+                                                                const double *__restrict__ part1, int C1, int slices1,
+                                                                int HW, int groups, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float eps,
+                                                                float *__restrict__ scale, float *__restrict__ shift) {
+    __shared__ double2 red[256];
+    __shared__ double2 chs[64];
+    const int n = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
+    const int C = C0 + C1, Cg = C / groups;         // Cg <= 64 (C <= 2048)
+    const int lanes = 256 / Cg;                     // slice lanes per channel
+    const int cc = t % Cg, l = t / Cg;
+    double a = 0, b = 0;
+    if (l < lanes) {
+        const int c = g * Cg + cc;
+        const bool first = c < C0;
+        const double *pp = first ? part0 : part1;
+        const int Cs = first ? C0 : C1, cl = first ? c : c - C0, sl = first ? slices0 : slices1;
+        const double *base = pp + ((size_t)n * sl * Cs + cl) * 2;
+        const size_t stride = (size_t)Cs * 2;
+        int s = l;
+        for (; s + 7 * lanes < sl; s += 8 * lanes) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(base + (size_t)(s + u * lanes) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += v[u].x; b += v[u].y; }
+        }
+        for (; s < sl; s += lanes) { const double2 v = *reinterpret_cast<const double2 *>(base + (size_t)s * stride); a += v.x; b += v.y; }
+    }
+    red[t] = make_double2(a, b);
+    __syncthreads();
+    if (t < Cg) {
+        double sa = 0, sb = 0;
+        for (int l2 = 0; l2 < lanes; ++l2) { const double2 v = red[l2 * Cg + t]; sa += v.x; sb += v.y; }
+        chs[t] = make_double2(sa, sb);
+    }
+    __syncthreads();
+    if (t < Cg) {
+        double sa = 0, sb = 0;
+        for (int k = 0; k < Cg; ++k) { sa += chs[k].x; sb += chs[k].y; }
+        const double cnt = (double)Cg * HW;
+        const double mean = sa / cnt;
+        const double var = fmax(sb / cnt - mean * mean, 0.0);
+        const float rstd = 1.0f / sqrtf((float)var + eps);
+        const int c = g * Cg + t;
+        const float sc = rstd * gamma[c];
+        scale[(size_t)n * C + c] = sc;
+        shift[(size_t)n * C + c] = beta[c] - (float)mean * sc;
+    }
+}
+
 } // namespace
 
 static int gn_slices(int B, int HW) {
@@ -177,6 +233,12 @@ void launch_groupnorm_affine(const TDesc &in0, const TDesc &in1, int B, int grou
 void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, int C1, int B, int HW, int groups,
                                const float *gamma, const float *beta, float eps, float *scale, float *shift,
                                hipStream_t s) {
+    // few images, many slices: one block per (image, group) instead of B x 4 blocks
+    if ((long)B * GN_FIN_GQ < 128 && std::max(s0.slices, s1.slices) >= 16 && (C0 + C1) / groups <= 64 && ((C0 + C1) % groups) == 0) {
+        hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B, groups), dim3(256), 0, s, s0.p, C0, s0.slices, s1.p, C1, s1.slices,
+                           HW, groups, gamma, beta, eps, scale, shift);
+        return;
+    }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B, groups % GN_FIN_GQ ? 1 : GN_FIN_GQ), dim3(256), 0, s, s0.p, C0, s0.slices,
                        s1.p, C1, s1.slices, HW, groups, gamma, beta, eps, scale, shift);
 }

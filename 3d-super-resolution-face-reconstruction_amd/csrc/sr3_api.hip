@@ -633,7 +633,11 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
     // profiles/README.md); below it the launch saved and the shorter critical path win
     const double pass_bytes = 8.0 * B * a.H * a.W * (a.C + (b.p ? b.C : 0));
     static const double fold_max = getenv("SR3_GN_FOLD_MAX_MB") ? atof(getenv("SR3_GN_FOLD_MAX_MB")) * 1e6 : 200e6;
-    if (sa.p && (!b.p || sb.p) && !c->no_fused_stats && pass_bytes > fold_max) {
+    // few images with many statistics slices (a single 128x128 image on 64x64 tiles leaves 256): the folded form's
+    // prologue walks them in 12-16 dependent round trips in EVERY block (12-23 us per apply at B = 1); the
+    // per-(image, group) finalize launch takes one round trip
+    const bool many_slices = (long)B * 4 < 128 && std::max(sa.slices, b.p ? sb.slices : 0) >= 64;
+    if (sa.p && (!b.p || sb.p) && !c->no_fused_stats && (pass_bytes > fold_max || many_slices)) {
         launch_groupnorm_finalize(sa, a.C, sb, b.p ? b.C : 0, B, a.H * a.W, c->cfg.norm_groups, gamma, beta, 1e-5f,
                                   c->gscale, c->gshift, c->stream);
         launch_gn_apply_rows(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split, c->d_ovf);

@@ -16,5 +16,8 @@ run_cfg --batch 32 --lres 32 --T 100 --steps 50
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_cfg3
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg3 -- python3 bench.py --image-size 128 --steps 5 --warmup 1 --no-alt --no-cpu-baseline --no-full-loop > gpurun_out/cfg3.log 2>&1
+# the "other" kernels of a step (copies / fills): with and without hipGraph replay
+rm -rf gpurun_out/prof_nograph
+SR3_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_nograph -- python3 bench.py --steps 5 --warmup 1 --no-alt --no-cpu-baseline --no-full-loop > gpurun_out/nograph.log 2>&1
 (python tools/step_profile.py --batch 1 --steps 30; python tools/step_profile.py --batch 4 --steps 30; python tools/step_profile.py --batch 4 --res 16 --lres 8 --T 100 --steps 30) > gpurun_out/small_batch.txt 2>&1
 tail -n 1 gpurun_out/bench_full.log | cut -c1-300
