@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the timed whole-loop sr3_sample call (N=1 only)")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=32)
     return ap.parse_args()
 
 
