@@ -345,6 +345,40 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // The statistics phase (6) runs in FRONT of the stores (4, 5): the producer threads' tail (adding the staged column sums,
+    // writing the slice) then runs under the consumers' store phase instead of after it, and the block leaves its CU
+    // slot that much earlier: 16.887 -> 16.780 ms per B = 64 step (three alternating pairs, -DSR3_EARLY_STATS=0 | 1
+    // builds of the same source; profiles/README.md finding 61)
+#ifndef SR3_EARLY_STATS
+#define SR3_EARLY_STATS 1
+#endif
+    constexpr bool EARLY = SR3_EARLY_STATS && !QRED && !GNF;
+    auto stats_phase = [&]() {
+    // 6. fused GroupNorm statistics of the stored values: fp64 column sums, handed to the producers
+        if (!GNF && p.stats != nullptr) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double st1 = 0.0, st2 = 0.0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double v = (double)acc[mt][nt][j];
+                        st1 += v; st2 = fma(v, v, st2);
+                    }
+                if (QRED) {
+                    st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+                    st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+                    if (q == 0) reinterpret_cast<double2 *>(smem)[wm * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+                } else {
+                    reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!QRED) __syncthreads();
+        }
+    };
+    if constexpr (EARLY) stats_phase();
     // 4. fp32 output (32-bit byte offsets: every tensor is < 4 GiB)
     if (!GNF && p.out_f32) {
         char *obase = reinterpret_cast<char *>(p.out.p);
@@ -383,29 +417,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
         }
         if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
     }
-    // 6. fused GroupNorm statistics of the stored values: fp64 column sums, handed to the producers
-    if (!GNF && p.stats != nullptr) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            double st1 = 0.0, st2 = 0.0;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double v = (double)acc[mt][nt][j];
-                    st1 += v; st2 = fma(v, v, st2);
-                }
-            if (QRED) {
-                st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
-                st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
-                if (q == 0) reinterpret_cast<double2 *>(smem)[wm * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
-            } else {
-                reinterpret_cast<double2 *>(smem)[(wm * 4 + q) * BN + wn * WN + nt * 16 + l16] = make_double2(st1, st2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!QRED) __syncthreads();
-    }
+    if constexpr (!EARLY) stats_phase();
 }
 
 // Producer side of the fused statistics: after the consumers' sums are in LDS, the producer
