@@ -1048,25 +1048,34 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
 #endif
         const int w = wid - 4;
         const int tid = threadIdx.x - 256;
-        if (tid < BM) {
-            const int m = min(m0 + tid, M - 1);
-            const int n = div_hw(p, m, HWo);
-            const int rem = m - n * HWo;
-            const int oy = div_w(p, rem, W);
-            rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
-            rowimg[tid] = n;
-        }
-        if constexpr (MS == 16) {           // column bias of the epilogue, fetched now, read from LDS later
-            const int img_a = div_hw(p, m0, HWo), img_b = div_hw(p, min(m0 + BM - 1, M - 1), HWo);
-            const bool one = img_a == img_b;
-            if (tid < BN) {
-                const int nc = min(n0 + tid, Cout - 1);
-                float v = p.bias ? p.bias[nc] : 0.f;
-                if (p.chan_bias != nullptr && one) v += p.chan_bias[(size_t)img_a * p.chan_bias_stride + nc];
-                colbias[tid] = v;
+        // Epilogue tables (row -> output pixel / image, column bias). They are not read before the epilogue, and the
+        // bias loads have a memory round trip of their own: with SR3_LATE_TABLES they are set up behind the DMAs of
+        // K-step 0 instead of in front of the first DMA (profiles/README.md finding 61).
+#ifndef SR3_LATE_TABLES
+#define SR3_LATE_TABLES 0
+#endif
+        auto setup_tables = [&]() {
+            if (tid < BM) {
+                const int m = min(m0 + tid, M - 1);
+                const int n = div_hw(p, m, HWo);
+                const int rem = m - n * HWo;
+                const int oy = div_w(p, rem, W);
+                rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
+                rowimg[tid] = n;
             }
-            if (tid == 0) reinterpret_cast<int *>(colbias)[BN] = one ? 1 : 0;
-        }
+            if constexpr (MS == 16) {           // column bias of the epilogue, fetched now, read from LDS later
+                const int img_a = div_hw(p, m0, HWo), img_b = div_hw(p, min(m0 + BM - 1, M - 1), HWo);
+                const bool one = img_a == img_b;
+                if (tid < BN) {
+                    const int nc = min(n0 + tid, Cout - 1);
+                    float v = p.bias ? p.bias[nc] : 0.f;
+                    if (p.chan_bias != nullptr && one) v += p.chan_bias[(size_t)img_a * p.chan_bias_stride + nc];
+                    colbias[tid] = v;
+                }
+                if (tid == 0) reinterpret_cast<int *>(colbias)[BN] = one ? 1 : 0;
+            }
+        };
+        if constexpr (!SR3_LATE_TABLES) setup_tables();
         const int rsub = lane >> 3;
         const unsigned schunk16 = (unsigned)(((lane & 7) ^ ((((w & 1) << 2) | (lane >> 4)) & 7)) * 16);
         const int Hp = p.in0.Hp(), Wp = p.in0.Wp();
@@ -1181,6 +1190,9 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                     if (zs == 1234.5f) rowimg[0] = 1;     // keep the chains alive
                 }
 #endif
+                if constexpr (SR3_LATE_TABLES && tap == 0) {
+                    if (c0 == cb) setup_tables();
+                }
                 if (!(SR3_DBG(p) & 8)) {                            // experiment bit 3: no barriers (timing only)
                     if (dx == 1 && halo_now) {
                         static_for<ARH + 1>([&](auto nc) {
