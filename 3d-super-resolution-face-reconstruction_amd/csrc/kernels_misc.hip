@@ -1337,65 +1337,6 @@ __global__ void ddpm_update_kernel(const UpdateParams u, size_t total) {
     if (sa.frame) sa.frame[i] = v;
 }
 
-// The same update with FOUR consecutive pixels of one (image, channel) row per thread (W % 4 == 0): they share one
-// Philox4x32-10 block (counter = element / 4), so it is evaluated once instead of four times — the kernel is bound by
-// that arithmetic. Every value is computed by the same operations as in the one-element kernel (bit-identical).
-__global__ void ddpm_update4_kernel(const UpdateParams u, size_t total4) {
-    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW/4, NCHW order
-    if (i4 >= total4) return;
-    const StepArgs sa = *u.args;
-    const int HW = u.state.H * u.state.W;
-    const size_t i = i4 * 4;
-    const int pp = (int)(i % HW);
-    const size_t nc = i / HW;
-    const int n = (int)(nc / u.C);
-    const int c = (int)(nc - (size_t)n * u.C);
-    const int y = pp / u.state.W, xx = pp - y * u.state.W;
-    float z[4] = {0.f, 0.f, 0.f, 0.f};
-    if (sa.sigma != 0.f) {
-        if (sa.noise) {
-            const float4 nz = *reinterpret_cast<const float4 *>(sa.noise + i);
-            z[0] = nz.x; z[1] = nz.y; z[2] = nz.z; z[3] = nz.w;
-        } else {
-            const uint32_t elem = (uint32_t)(c * HW + pp);
-            const uint64_t image = sa.image_offset + n;
-            uint32_t r[4];
-            philox4x32_10(elem >> 2, sa.draw, (uint32_t)image, (uint32_t)(image >> 32), (uint32_t)sa.seed, (uint32_t)(sa.seed >> 32), r);
-#pragma unroll
-            for (int pair = 0; pair < 2; ++pair) {
-                const float u1 = ((float)(r[2 * pair] >> 8) + 0.5f) * 5.9604644775390625e-08f;      // 2^-24
-                const float u2 = ((float)(r[2 * pair + 1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
-                const float rad = sqrtf(-2.0f * logf(u1));
-                const float th = 6.283185307179586f * u2;
-                z[2 * pair] = rad * cosf(th);
-                z[2 * pair + 1] = rad * sinf(th);
-            }
-        }
-    }
-    float vout[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const size_t pix = u.state.pix(n, y, xx + j);
-        const size_t si = pix * u.state.C + u.xoff + c;
-        const float x = u.state.p[si];
-        const float e = u.eps.p[u.eps.pix(n, y, xx + j) * u.eps.C + c];
-        float x0 = __fsub_rn(__fmul_rn(sa.a, x), __fmul_rn(sa.b, e));
-        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-        float v = __fadd_rn(__fmul_rn(sa.c1, x0), __fmul_rn(sa.c2, x));
-        if (sa.sigma != 0.f) v = __fadd_rn(v, __fmul_rn(z[j], sa.sigma));
-        u.state.p[si] = v;
-        if (u.packed != nullptr) {
-            _Float16 *pk = reinterpret_cast<_Float16 *>(u.packed) + pix * 16 + u.xoff + c;
-            const _Float16 hi = (_Float16)v;
-            pk[0] = hi;
-            pk[8] = (_Float16)(v - (float)hi);
-            if (u.ovf != nullptr && ((unsigned)__builtin_bit_cast(unsigned short, hi) & 0x7C00u) == 0x7C00u) *u.ovf = 1;
-        }
-        vout[j] = v;
-    }
-    if (sa.frame) *reinterpret_cast<float4 *>(sa.frame + i) = make_float4(vout[0], vout[1], vout[2], vout[3]);
-}
-
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 } // namespace
@@ -1412,10 +1353,6 @@ void launch_nhwc_to_nchw(const TDesc &src, int coff, int B, int C, float *out, h
 }
 void launch_ddpm_update(const UpdateParams &p, int B, hipStream_t s) {
     const size_t total = (size_t)B * p.C * p.state.H * p.state.W;
-    if ((p.state.W % 4) == 0) {     // four pixels of a row per thread: one Philox block for the four
-        hipLaunchKernelGGL(ddpm_update4_kernel, dim3(nblk(total / 4)), dim3(256), 0, s, p, total / 4);
-        return;
-    }
     hipLaunchKernelGGL(ddpm_update_kernel, dim3(nblk(total)), dim3(256), 0, s, p, total);
 }
 void launch_init_state(const TDesc &state, int xoff, int C, const float *noise, uint64_t seed,
