@@ -39,7 +39,9 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 8), (2, 5), (3, 7)])
+# (8, 512) and (8, 256): the global batches of BASELINE configs 4 and 5 (sr_sr3_VGGF2_8_128 / 32_128 on 8 GPUs: 64 and 32
+# images per rank) — the 8-rank control flow of north_star's design, rehearsed over gloo on CPU; (8, 250): a ragged split
+@pytest.mark.parametrize("world,n", [(2, 8), (2, 5), (3, 7), (8, 512), (8, 256), (8, 250)])
 def test_sharded_gather(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
