@@ -194,6 +194,30 @@ def test_packed_state_overflow_from_injected_noise_is_caught():
     e.close()
 
 
+def test_final_conv_on_the_fly_split_is_range_checked():
+    """final_conv builds its split-f16 operands on the fly (GroupNorm + Swish inside the kernel); a value beyond
+    the fp16 range there must raise the flag like every stored one. A huge final GroupNorm gamma makes swish(a x + b)
+    ~1e6: the default policy finishes the forward in f32 (== oracle), the strict policy fails."""
+    cfg = synth.tiny_unet_config()
+    sd = synth.synth_state_dict(cfg, 21)
+    sd["final_conv.block.0.weight"] = sd["final_conv.block.0.weight"] * np.float32(3e5)
+    sd["final_conv.block.3.weight"] = sd["final_conv.block.3.weight"] * np.float32(1e-5)     # keep eps O(1)
+    rs = np.random.RandomState(6)
+    x = rs.standard_normal((2, 6, 16, 16)).astype(np.float32)
+    nl = np.array([0.4, 0.6], np.float32)
+    want = oracle.unet_forward(sd, cfg, x, nl)
+    e = _engine(cfg, sd, "f16x3")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = e.unet_forward_np(x, nl)
+    assert any(issubclass(w.category, Sr3RangeWarning) for w in rec), "the on-the-fly split did not raise the range flag"
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    e.set_range_policy(True)
+    with pytest.raises(Sr3Error, match="fp16 range"):
+        e.unet_forward_np(x, nl)
+    e.close()
+
+
 def test_facade_finishes_overflowing_calls():
     """define_G facade, default policy: super_resolution / denoise_fn / p_sample finish like the reference."""
     import torch
