@@ -448,7 +448,7 @@ __device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const f
 // add that returns 3G - 1 stores 0, ready for the next launch — nobody polls any more by then).
 // No wait can hang by construction: a block only waits for blocks of its own group, which launch_conv orders so that
 // they are dispatched together (see conv_gnf_supported); should the hardware ever dispatch differently, the poll gives
-// up after ~2 s, raises SR3_FLAG_GNF_TIMEOUT in *ovf (the API call fails) and the grid drains.
+// up after 2^28 shader cycles (> 0.1 s), raises SR3_FLAG_GNF_TIMEOUT in *ovf (the API call fails) and the grid drains.
 typedef unsigned __attribute__((address_space(1))) *gnf_cnt_ptr;
 typedef const double __attribute__((address_space(1))) *gnf_cdbl_ptr;
 typedef double __attribute__((address_space(1))) *gnf_dbl_ptr;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void gnf_producer_tail(const ConvParams &p, float *sm
             const long long t0 = __builtin_amdgcn_s_memtime();
             while (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(16);
-                if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {     // ~2.7 s of the 100 MHz counter: never in a healthy run
+                if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {     // 2^28 shader cycles (> 0.1 s): never in a healthy run
                     if (p.ovf != nullptr) atomicOr(p.ovf, SR3_FLAG_GNF_TIMEOUT);
                     break;
                 }
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                     const long long t0 = __builtin_amdgcn_s_memtime();
                     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsplit) {
                         __builtin_amdgcn_s_sleep(8);
-                        if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {        // ~2.7 s: never in a healthy run
+                        if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {        // 2^28 shader cycles (> 0.1 s): never in a healthy run
                             if (p.ovf != nullptr) atomicOr(p.ovf, SR3_FLAG_GNF_TIMEOUT);
                             break;
                         }

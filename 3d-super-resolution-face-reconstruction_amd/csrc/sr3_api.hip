@@ -1402,6 +1402,12 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
         c->ckpt_floats = slab;
     }
     auto save = [&]() { launch_nhwc_to_nchw(c->x0, nc, B, C, c->ckpt, c->stream); };
+    // back to the last clean boundary, exact f32 from here on (the mode is restored before the call returns)
+    auto fall_back = [&]() {
+        launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
+        if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
+        c->prec = 0;
+    };
     int t_ck = T - 1, f_ck = 0;          // the checkpoint holds the state BEFORE step t_ck; f_ck frames were written by then
     bool fell_back = false;
     int rc = 0;
@@ -1417,9 +1423,7 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
             const int r = range_read(c);
             if (r < 0) { rc = -1; break; }
             if (r > 0) {
-                launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
-                if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
-                c->prec = 0; fell_back = true;
+                fall_back(); fell_back = true;
                 t = t_ck; f = f_ck;
             } else {
                 save();
@@ -1434,9 +1438,7 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
             const int r = range_read(c);
             if (r < 0) { rc = -1; break; }
             if (r > 0) {
-                launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
-                if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
-                c->prec = 0; fell_back = true;
+                fall_back(); fell_back = true;
                 t = t_ck + 1; f = f_ck;             // (the loop's --t resumes at t_ck)
             }
         }
