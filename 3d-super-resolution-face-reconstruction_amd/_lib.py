@@ -57,6 +57,7 @@ PROTOTYPES = {
     "sr3_wait_for_stream": (_I, [_P, _P]),
     "sr3_stream_wait_for_ctx": (_I, [_P, _P]),
     "sr3_set_precision": (_I, [_P, _I]),
+    "sr3_conv_f8_supported": (_I, [_I, _I, _I, _I, _I]),
     "sr3_num_params": (_I, [_P]),
     "sr3_param_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(_I)]),
     "sr3_load_weight": (_I, [_P, C.c_char_p, _F, C.POINTER(C.c_int64), _I]),

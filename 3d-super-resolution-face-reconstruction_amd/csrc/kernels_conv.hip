@@ -43,6 +43,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // memcpys via scratch memory)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -418,6 +420,122 @@ __device__ __forceinline__ void conv_epilogue16(const ConvParams &p, f32x4 (&acc
         if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
     }
     if constexpr (!EARLY) stats_phase();
+}
+
+// conv_epilogue16's phase structure for 32x32 accumulator tiles (the F8C consumers of the x-halo kernel): C/D map
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5). Whole tiles (M % BM == 0, Cout % BN == 0), no
+// split-K. colbias / one_img as in conv_epilogue16; the statistics go to the producers FIRST (finding 61), staged as
+// [wm * 2 + lh][column] entries (producer_stats_tail<BM, BN, WGM, 2>). The per-element form (conv_epilogue_impl) cost
+// these kernels ~17 % of their time inside the step (finding 64).
+template <int BM, int BN, int WGM, int WGN, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue32(const ConvParams &p, f32x16 (&acc)[MI][NI], float *smem,
+                                                const int *rowpix, const int *rowimg, int wm, int wn, int li, int lh,
+                                                int n0, const float *colbias, const bool one_img) {
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    const unsigned Cout = (unsigned)p.out.C;
+    const unsigned ncol = (unsigned)(n0 + wn * WN + li);        // column of ni = 0; + 32 per ni
+    // rows of accumulator registers 4 rq .. 4 rq + 3 of row tile mi: wm * WM + mi * 32 + 8 rq + 4 lh + j
+    auto rows4 = [&](const int *tab, int mi, int rq) {
+        return *reinterpret_cast<const int4 *>(tab + wm * WM + mi * 32 + 8 * rq + 4 * lh);
+    };
+    // 1. column bias
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const float bs = colbias[wn * WN + ni * 32 + li];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bs;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. FeatureWiseAffine bias per row (tiles that span several images)
+    if (p.chan_bias != nullptr && !one_img) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int4 ri = rows4(rowimg, mi, rq);
+                const int im[4] = {ri.x, ri.y, ri.z, ri.w};
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mi][ni][4 * rq + j] += p.chan_bias[(size_t)im[j] * p.chan_bias_stride + ncol + ni * 32];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    // 3. residual (fp32 tensor, or hi + lo of a split-only tensor)
+    if (p.resid.p != nullptr) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int4 rp = rows4(rowpix, mi, rq);
+                const unsigned rb[4] = {(unsigned)rp.x * Cout, (unsigned)rp.y * Cout, (unsigned)rp.z * Cout, (unsigned)rp.w * Cout};
+                if (p.resid_split) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[mi][ni][4 * rq + j] += load_split(p.resid.p, rb[j] + ncol + ni * 32);
+                } else {
+                    const char *rbase = reinterpret_cast<const char *>(p.resid.p);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mi][ni][4 * rq + j] += *reinterpret_cast<const float *>(rbase + (rb[j] + ncol + ni * 32) * 4u);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // 4 rows x NI columns in flight at a time
+            }
+    }
+    // 6. fused GroupNorm statistics of the stored values, handed to the producers before the stores
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            double st1 = 0.0, st2 = 0.0;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double v = (double)acc[mi][ni][r];
+                    st1 += v; st2 = fma(v, v, st2);
+                }
+            reinterpret_cast<double2 *>(smem)[(wm * 2 + lh) * BN + wn * WN + ni * 32 + li] = make_double2(st1, st2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // 4. fp32 output, 5. split-f16 twin (lanes li, li ^ 1 hold neighbouring channels: one 4-byte word per lane)
+    const unsigned psel = split_pair_selector(li & 1);
+    char *obase = reinterpret_cast<char *>(p.out.p);
+    char *tlane = reinterpret_cast<char *>(p.out_split.p) + (((li & 1) ? 16u : 0u) + ((unsigned)li >> 1)) * 4u;
+    const unsigned cb = (unsigned)(n0 + wn * WN) * 4u;          // byte offset of the wave's first 32-channel chunk
+    unsigned range_bits = 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int4 rp = rows4(rowpix, mi, rq);
+            const unsigned rb[4] = {(unsigned)rp.x * Cout, (unsigned)rp.y * Cout, (unsigned)rp.z * Cout, (unsigned)rp.w * Cout};
+            if (p.out_f32) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float *>(obase + (rb[j] + ncol + ni * 32) * 4u) = acc[mi][ni][4 * rq + j];
+            }
+            if (p.out_split.p != nullptr) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned word = split_pair_word(acc[mi][ni][4 * rq + j], psel, range_bits);
+                        *reinterpret_cast<unsigned *>(tlane + rb[j] * 4u + cb + ni * 128u) = word;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    if (p.out_split.p != nullptr && p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
 }
 
 // Producer side of the fused statistics: after the consumers' sums are in LDS, the producer
@@ -955,8 +1073,9 @@ __global__ __launch_bounds__(512, (((BM + BN) * ROWF * 4 * NS + 8 * BM) * 3 <= 1
 // SPK: in-place split-K instantiation (ConvParams::splits > 1; MS == 16, KS == 3). A template parameter, not a run-time
 // branch: with the split code compiled into the one kernel the register allocation of the unsplit K loop changed
 // (scratch 76 -> 430 bytes per lane) and EVERY x-halo conv ran 20 % slower (same box: 16.35 -> 19.29 ms per B = 64 step).
-template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false, bool SPK = false>
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false, bool SPK = false, bool F8C = false>
 __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) void conv3x3_halo_h3(const ConvParams p_in) {
+    static_assert(!F8C || (MS == 32 && KS == 3 && !GNF && !SPK), "fp8 correction products: 3x3 convs on the 32x32 consumers");
     static_assert(!GNF || (MS == 16 && KS == 3), "producer-side GroupNorm: 3x3 convs on the 16x16x32 consumers");
     static_assert(!SPK || (MS == 16 && KS == 3 && !GNF), "in-place split-K: 3x3 convs on the 16x16x32 consumers");
     const ConvParams p = phase_params(p_in, blockIdx.z);
@@ -1063,7 +1182,7 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                 rowpix[tid] = (int)p.out.pix(n, oy * p.out_step + p.out_oy, (rem - oy * W) * p.out_step + p.out_ox);
                 rowimg[tid] = n;
             }
-            if constexpr (MS == 16) {           // column bias of the epilogue, fetched now, read from LDS later
+            if constexpr (MS == 16 || F8C) {    // column bias of the epilogue, fetched now, read from LDS later
                 const int img_a = div_hw(p, m0, HWo), img_b = div_hw(p, min(m0 + BM - 1, M - 1), HWo);
                 const bool one = img_a == img_b;
                 if (tid < BN) {
@@ -1574,12 +1693,9 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
     // B rows are plain: the swizzle term is a per-lane constant
     const int swzB = (li >> 1) & 7;
     const float *Bbase = Bring + (wn * WN + li) * ROWF;
-    int hoffB[2], loffB[2];
+    int hoffB[2];
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-        hoffB[sb] = (((2 * sb + lh) ^ swzB) & 7) * 4;
-        loffB[sb] = (((4 + 2 * sb + lh) ^ swzB) & 7) * 4;
-    }
+    for (int sb = 0; sb < 2; ++sb) hoffB[sb] = (((2 * sb + lh) ^ swzB) & 7) * 4;
     // A rows: halo row of tile row r for dx = 0 is r + 2 * (r / SEG); plain row (in2 phase) is r.
     // (Precomputing per-(mi, dx) offsets and unrolling the three taps was measured slower: more
     // registers, lower occupancy for the 128x64 tile.)
@@ -1589,7 +1705,14 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         rplain[mi] = wm * WM + mi * 32 + li;
         rhalo[mi] = rplain[mi] + HALO * (rplain[mi] / SEG);
     }
-    h16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+    // second halves of the rows (lo halfs, or fp8 operands in F8C K-steps): both 16-wide K blocks of a K-step side by side
+    // in ONE 8-register tuple, so that the fp8 MFMA takes it as it is and the f16 MFMAs take its halves
+    h16x8 ah[2][MI], bh[2][NI];
+    i32x8 al8[MI], bl8[NI];
+    auto half_of = [](const i32x8 &v, auto set_c) {
+        constexpr int S = decltype(set_c)::value;
+        return __builtin_bit_cast(h16x8, __builtin_shufflevector(v, v, 4 * S, 4 * S + 1, 4 * S + 2, 4 * S + 3));
+    };
     // fragment reads of K-step KT, 16-wide K block SB into register set SET
 #define SR3_HREAD(SET, KT, SB)                                                                     \
     {                                                                                              \
@@ -1600,34 +1723,71 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         const int dx_ = kt_ - KS * g_;                                                             \
         const float *Ab_ = Aring + astage_ * ASTG;                                                 \
         const float *Bb_ = Bbase + (kt_ & 1) * BSTG;                                               \
+        /* second half of a row: chunk 4 + 2 SB + lh. f16x3: the lo halfs of K block SB. F8C halo K-steps: the same two    \
+           chunks ARE the lane's fp8 operand — v_mfma_scale_f32_32x32x64_f8f6f4 takes bytes 0..15 of a lane as K elements    \
+           16 lh .. 16 lh + 15 of scale block 0 and bytes 16..31 as those of scale block 1 (measured: tools/f8_mfma_probe) */ \
+        const int c2_ = 4 + 2 * (SB) + lh;                                                         \
         _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                        \
             const int R_ = halo_ ? rhalo[mi] + dx_ : rplain[mi];                                   \
             const int sw_ = (R_ >> 1) & 7;                                                         \
             ah[SET][mi] = *reinterpret_cast<const h16x8 *>(Ab_ + R_ * ROWF + (((2 * (SB) + lh) ^ sw_) & 7) * 4);     \
-            al[SET][mi] = *reinterpret_cast<const h16x8 *>(Ab_ + R_ * ROWF + (((4 + 2 * (SB) + lh) ^ sw_) & 7) * 4); \
+            const i32x4 t_ = *reinterpret_cast<const i32x4 *>(Ab_ + R_ * ROWF + ((c2_ ^ sw_) & 7) * 4); \
+            al8[mi][4 * (SET)] = t_[0]; al8[mi][4 * (SET) + 1] = t_[1]; al8[mi][4 * (SET) + 2] = t_[2]; al8[mi][4 * (SET) + 3] = t_[3]; \
         }                                                                                          \
+        const int lob_ = ((c2_ ^ swzB) & 7) * 4;                                                   \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
             bh[SET][ni] = *reinterpret_cast<const h16x8 *>(Bb_ + ni * 32 * ROWF + hoffB[SB]);      \
-            bl[SET][ni] = *reinterpret_cast<const h16x8 *>(Bb_ + ni * 32 * ROWF + loffB[SB]);      \
+            const i32x4 t_ = *reinterpret_cast<const i32x4 *>(Bb_ + ni * 32 * ROWF + lob_);        \
+            bl8[ni][4 * (SET)] = t_[0]; bl8[ni][4 * (SET) + 1] = t_[1]; bl8[ni][4 * (SET) + 2] = t_[2]; bl8[ni][4 * (SET) + 3] = t_[3]; \
         }                                                                                          \
     }
-#define SR3_HMMA(SET)                                                                              \
+    // F8C (ConvParams::f8): in the halo K-steps the second half of a row holds fp8 operands — (xl8 | xh8) for A, (wh8 | wl8)
+    // for B = scale blocks 0 | 1 of the instruction — and ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile and K-step
+    // computes xl*wh + xh*wl (64 cycles instead of the 128 of four f16 MFMAs); the power-of-two operand scales (SR3_F8_*)
+    // come back through the block-scale operands (scale block j is taken from lane half lh = j). Fused 1x1 K-steps stay f16x3.
+#define SR3_HMMA(SET, F8K)                                                                         \
     {                                                                                              \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bl[SET][ni], acc[mi][ni], 0, 0, 0); \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+        if (F8C && (F8K)) {                                                                        \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                      \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+            if ((SET) == 0) {                                                                      \
+                _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                  \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                  \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al8[mi], bl8[ni], acc[mi][ni], 0, 0, 0, f8_scale_a, 0, f8_scale_b); \
+            }                                                                                      \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                    \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(half_of(al8[mi], std::integral_constant<int, (SET)>{}), bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], half_of(bl8[ni], std::integral_constant<int, (SET)>{}), acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+            }                                                                                      \
         }                                                                                          \
     }
+    // E8M0 block scales of the fp8 product: scale block 0 (from lanes lh = 0) is xl8 * wh8, block 1 (lh = 1) is xh8 * wl8
+    const int f8_scale_a = lh == 0 ? 127 - SR3_F8_XL : 127 - SR3_F8_XH, f8_scale_b = lh == 0 ? 127 - SR3_F8_WH : 127 - SR3_F8_WL;
+    (void)f8_scale_a; (void)f8_scale_b;
     __syncthreads();
     SR3_HREAD(0, 0, 0)
-    for (int kt = 0; kt < nk; ++kt) {
+    int kt = 0;
+    if constexpr (F8C) {
+        // halo K-steps: corrections on the fp8 path (issued with set 0). A loop of its own — a run-time choice between the
+        // two MFMA sequences inside one loop made the compiler spill the accumulators at the merge points.
+        for (; kt < nkh; ++kt) {
+            SR3_HREAD(1, kt, 1)
+            SR3_HMMA(0, true)
+            __syncthreads();
+            SR3_HREAD(0, min(kt + 1, nk - 1), 0)
+            SR3_HMMA(1, true)
+        }
+    }
+    for (; kt < nk; ++kt) {
         SR3_HREAD(1, kt, 1)
-        SR3_HMMA(0)
+        SR3_HMMA(0, false)
         __syncthreads();                       // every read of tile kt has been issued and waited
         SR3_HREAD(0, min(kt + 1, nk - 1), 0)   // next tile (re-reads the last one at the end: unused)
-        SR3_HMMA(1)
+        SR3_HMMA(1, false)
     }
 #undef SR3_HREAD
 #undef SR3_HMMA
@@ -1637,7 +1797,11 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= p.w_unscale;
-    conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, 0, 1);
+    if constexpr (F8C)
+        conv_epilogue32<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, wm, wn, li, lh, n0, colbias,
+                                                  reinterpret_cast<const int *>(colbias)[BN] != 0);
+    else
+        conv_epilogue<BM, BN, WGM, WGN, MI, NI>(p, acc, smem, rowpix, rowimg, m0, n0, M, wm, wn, li, lh, 0, 1);
 }
 
 #ifdef SR3_EXPERIMENTS
@@ -2044,14 +2208,14 @@ void launch_halo_pt(const ConvParams &p, hipStream_t s) {
 
 #endif  // SR3_EXPERIMENTS
 
-template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false, bool SPK = false>
+template <int BM, int BN, int WGM, int WGN, int SEGMIN, int KS, int MS, bool GNF = false, bool SPK = false, bool F8C = false>
 void launch_halo(const ConvParams &p, hipStream_t s) {
     static bool attr_set = false;
     constexpr int RA = (BM + (KS - 1) * (BM / SEGMIN) + 7) / 8 * 8;
     constexpr size_t lds = ((size_t)2 * RA * ROWF + 2 * BN * ROWF + 2 * BM + BN + 4) * sizeof(float);
     // (the GroupNorm hand-off stages its sums, scale / shift and the fold scratch in the rings, free after the K loop)
     static_assert(!GNF || ((size_t)WGM * 4 * BN * 16 + BN * 8 + 4096 + 16 <= ((size_t)2 * RA * ROWF + 2 * BN * ROWF) * sizeof(float)), "GNF staging fits the rings");
-    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS, GNF, SPK>;
+    auto kern = conv3x3_halo_h3<BM, BN, WGM, WGN, SEGMIN, KS, MS, GNF, SPK, F8C>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2283,6 +2447,22 @@ int conv_halo_splits(long M, int H, int W, int Cout, int Cin) {
     return sp;
 }
 
+// F8C ("f16f8" mode): 3x3 / stride-1 split-f16 convs that run on the 128x128 x-halo tile without split-K at the 32x32- and
+// 16x16-pixel levels — the MFMA-bound shapes, where the 32x32 consumers with the corrections on the fp8 path measured
+// 14-20 % faster than the f16x3 kernel (profiles/README.md finding 64); the 64x64- and 128x128-pixel levels are bound by
+// operand movement and gain nothing. Mirrors launch_conv's choice: callers format the conv's input accordingly.
+bool conv_f8_supported(int B, int H, int W, int Cout, int Cin) {
+    static const int off = getenv("SR3_NO_F8C") ? atoi(getenv("SR3_NO_F8C")) : 0;
+    static const int maxhw = getenv("SR3_F8C_MAX_HW") ? atoi(getenv("SR3_F8C_MAX_HW")) : 1024;
+    const long M = (long)B * H * W;
+    const int HWo = H * W;
+    if (off || (Cin % 32) || (Cout % 128) || (M % 128) || HWo > maxhw || HWo < 128 || (HWo % 128)) return false;
+    const int seg = W < 128 ? W : 128;
+    if (seg < 8 || (W % seg) || (128 % seg)) return false;
+    if (conv_tile_choice(M, Cout) != 3) return false;
+    return conv_halo_splits(M, H, W, Cout, Cin) <= 1;
+}
+
 bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases) {
     static const int off = getenv("SR3_NO_INPLACE_SPLIT") ? atoi(getenv("SR3_NO_INPLACE_SPLIT")) : 0;
     if (off || conv_splits(M, Cout, Cin) <= 1) return false;
@@ -2390,6 +2570,15 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         return;
     }
 #endif
+    if (p.f8) {
+        // the caller asked conv_f8_supported() first and wrote the input / passes the weights in the F8C format
+        if (!(p.prec == 1 && p.ks == 3 && p.phases == 1 && p.splits <= 1 && halo_ok(p, 128, 8, 128))) {
+            fprintf(stderr, "sr3: internal: fp8 correction products requested for an unsupported conv\n");
+            abort();
+        }
+        launch_halo<128, 128, 2, 2, 8, 3, 32, false, false, true>(p, s);
+        return;
+    }
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
@@ -2460,6 +2649,35 @@ void make_up2_phase_weights(const float *w9, int Cout, int CinPad, float *dst) {
                         d[i] = (float)acc;
                     }
                 }
+}
+
+namespace {
+// one thread = 4 channels of a 32-channel chunk: split weights (32 hi halfs | 32 lo halfs) -> F8C weights
+// (32 hi halfs | 32 x e4m3(hi * 2^SR3_F8_WH) | 32 x e4m3(lo * 2^SR3_F8_WL))
+__global__ __launch_bounds__(256) void make_f8_weights_kernel(const float *__restrict__ split, float *__restrict__ dst, size_t chunks) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= chunks * 8) return;
+    const size_t ch = t >> 3;
+    const int j = (int)(t & 7) * 4;
+    const _Float16 *src = reinterpret_cast<const _Float16 *>(split + ch * 32);
+    _Float16 *dh = reinterpret_cast<_Float16 *>(dst + ch * 32);
+    unsigned char *d8 = reinterpret_cast<unsigned char *>(dst + ch * 32) + 64;
+    float h[4], l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { h[u] = (float)src[j + u]; l[u] = (float)src[32 + j + u]; dh[j + u] = src[j + u]; }
+    const float sh = ldexpf(1.0f, SR3_F8_WH), sl = ldexpf(1.0f, SR3_F8_WL);
+    auto cl = [](float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); };
+    int wh = __builtin_amdgcn_cvt_pk_fp8_f32(cl(h[0] * sh), cl(h[1] * sh), 0, false);
+    wh = __builtin_amdgcn_cvt_pk_fp8_f32(cl(h[2] * sh), cl(h[3] * sh), wh, true);
+    int wl = __builtin_amdgcn_cvt_pk_fp8_f32(cl(l[0] * sl), cl(l[1] * sl), 0, false);
+    wl = __builtin_amdgcn_cvt_pk_fp8_f32(cl(l[2] * sl), cl(l[3] * sl), wl, true);
+    *reinterpret_cast<int *>(d8 + j) = wh;
+    *reinterpret_cast<int *>(d8 + 32 + j) = wl;
+}
+} // namespace
+
+void launch_make_f8_weights(const float *split, float *dst, size_t chunks, hipStream_t s) {
+    hipLaunchKernelGGL(make_f8_weights_kernel, dim3((unsigned)((chunks * 8 + 255) / 256)), dim3(256), 0, s, split, dst, chunks);
 }
 
 void pack_conv_weight(const float *oihw, int Cout, int Cin, int ks, int CinPad, float *dst) {

@@ -255,22 +255,46 @@ __device__ __forceinline__ float swish_fast(float x) {
     return x * __frcp_rn(1.0f + __expf(-x));
 }
 
+// e4m3 (OCP) pair conversion: v_cvt_pk_fp8_f32 into the low / high half of a word; inputs clamped to the format's
+// finite range (the callers raise the range flag for values that would saturate)
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    auto cl = [](float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); };
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+    return (unsigned)w;
+}
+
+// SPLIT 0: fp32; 1: split-f16 (hi | lo halfs); 2: the F8C variant (hi halfs | e4m3 of lo | e4m3 of hi; ConvParams::f8)
 template <int SPLIT>
 __device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8], float &absmax) {
     if (SPLIT) {
         // chunk of 32 channels = 128 B: halfs [0,32) hi, [32,64) lo; x = hi + lo to ~2^-22 |x|.
         // Values beyond the fp16 range are not clamped but detected (absmax -> the ovf flag).
         h16x8 hi, lo;
+        float lof[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float g = f[j];
             absmax = fmaxf(absmax, fabsf(g));
             hi[j] = (_Float16)g;
-            lo[j] = (_Float16)(g - (float)hi[j]);
+            lof[j] = g - (float)hi[j];
+            lo[j] = (_Float16)lof[j];
         }
         _Float16 *hd = reinterpret_cast<_Float16 *>(dst + (c & ~31)) + (c & 31);
         *reinterpret_cast<h16x8 *>(hd) = hi;
-        *reinterpret_cast<h16x8 *>(hd + 32) = lo;
+        if (SPLIT == 2) {
+            constexpr float SL = (float)(1 << SR3_F8_XL), SH = (float)(1 << SR3_F8_XH);
+            unsigned char *b8 = reinterpret_cast<unsigned char *>(dst + (c & ~31)) + 64 + (c & 31);
+            uint2 l8, h8;
+            l8.x = pack4_e4m3(lof[0] * SL, lof[1] * SL, lof[2] * SL, lof[3] * SL);
+            l8.y = pack4_e4m3(lof[4] * SL, lof[5] * SL, lof[6] * SL, lof[7] * SL);
+            h8.x = pack4_e4m3((float)hi[0] * SH, (float)hi[1] * SH, (float)hi[2] * SH, (float)hi[3] * SH);
+            h8.y = pack4_e4m3((float)hi[4] * SH, (float)hi[5] * SH, (float)hi[6] * SH, (float)hi[7] * SH);
+            *reinterpret_cast<uint2 *>(b8) = l8;
+            *reinterpret_cast<uint2 *>(b8 + 32) = h8;
+        } else {
+            *reinterpret_cast<h16x8 *>(hd + 32) = lo;
+        }
     } else {
         *reinterpret_cast<float4 *>(dst + c) = make_float4(f[0], f[1], f[2], f[3]);
         *reinterpret_cast<float4 *>(dst + c + 4) = make_float4(f[4], f[5], f[6], f[7]);
@@ -375,7 +399,7 @@ __global__ __launch_bounds__(GA_T) void gn_apply_kernel(const TDesc in0, const T
     const int pl = t / TC;
     if (pl >= rows) return;
     const int pix0 = blockIdx.x * ppb, pix1 = min(HW, pix0 + ppb);
-    float absmax = 0.f;
+    float absmax = 0.f, absmax_raw = 0.f;
     for (int c = (t - pl * TC) << 3; c < C; c += TC << 3) {       // one pass unless C8 > GA_T
         float scv[8], shv[8];
         if (MODE != 0) {
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(GA_T) void gn_apply_kernel(const TDesc in0, const T
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { f[j] = it.a[j]; f[4 + j] = it.b[j]; }
             }
-            if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f, absmax);
+            if (raw.p != nullptr) store8<(SPLIT ? 1 : 0)>(raw.p + raw.pix(n, y, x) * C, c, f, absmax_raw);
             if (MODE != 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], scv[j], shv[j]);
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(GA_T) void gn_apply_kernel(const TDesc in0, const T
             while (x >= W) { x -= W; ++y; }
         }
     }
-    if (SPLIT && ovf != nullptr && absmax > SPLIT_F16_MAX) *ovf = 1;
+    if (SPLIT && ovf != nullptr && (absmax > (SPLIT == 2 ? SPLIT_F8_MAX : SPLIT_F16_MAX) || absmax_raw > SPLIT_F16_MAX)) *ovf = 1;
 }
 
 } // namespace
@@ -496,7 +520,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, con
         scv[0] = s0.x; scv[1] = s0.y; scv[2] = s0.z; scv[3] = s0.w; scv[4] = s1.x; scv[5] = s1.y; scv[6] = s1.z; scv[7] = s1.w;
         shv[0] = h0.x; shv[1] = h0.y; shv[2] = h0.z; shv[3] = h0.w; shv[4] = h1.x; shv[5] = h1.y; shv[6] = h1.z; shv[7] = h1.w;
     }
-    float absmax = 0.f;
+    float absmax = 0.f, absmax_raw = 0.f;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int y = y0 + r * Hh;
@@ -509,7 +533,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) { f[j] = la[r][j]; f[4 + j] = lb[r][j]; }
         }
-        if (raw.p != nullptr) store8<SPLIT>(raw.p + raw.pix(n, y, x) * C, c, f, absmax);
+        if (raw.p != nullptr) store8<(SPLIT ? 1 : 0)>(raw.p + raw.pix(n, y, x) * C, c, f, absmax_raw);
         if (MODE != 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = fmaf(f[j], scv[j], shv[j]);
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, con
         }
         store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
     }
-    if (SPLIT && ovf != nullptr && absmax > SPLIT_F16_MAX) *ovf = 1;
+    if (SPLIT && ovf != nullptr && (absmax > (SPLIT == 2 ? SPLIT_F8_MAX : SPLIT_F16_MAX) || absmax_raw > SPLIT_F16_MAX)) *ovf = 1;
 }
 } // namespace
 
@@ -534,7 +558,9 @@ void launch_gn_apply_rows(const TDesc &in0, const TDesc &in1, int B, const float
         if (nr == 2) hipLaunchKernelGGL((gn_apply_rows_kernel<M, S, 2>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf); \
         else hipLaunchKernelGGL((gn_apply_rows_kernel<M, S, 1>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf);         \
     }
-    if (split) {
+    if (split == 2) {
+        if (mode == 0) SR3_GR(0, 2) else if (mode == 1) SR3_GR(1, 2) else SR3_GR(2, 2)
+    } else if (split) {
         if (mode == 0) SR3_GR(0, 1) else if (mode == 1) SR3_GR(1, 1) else SR3_GR(2, 1)
     } else {
         if (mode == 0) SR3_GR(0, 0) else if (mode == 1) SR3_GR(1, 0) else SR3_GR(2, 0)
@@ -576,7 +602,9 @@ static void launch_gn_apply_impl(const TDesc &in0, const TDesc &in1, int B, cons
         hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(GA_T), lds, s, in0, in1, scale, shift, st, out, raw, \
                            in_split, ovf, ppb);                                                                    \
     }
-    if (split) {
+    if (split == 2) {
+        if (mode == 0) SR3_GA(0, 2) else if (mode == 1) SR3_GA(1, 2) else SR3_GA(2, 2)
+    } else if (split) {
         if (mode == 0) SR3_GA(0, 1) else if (mode == 1) SR3_GA(1, 1) else SR3_GA(2, 1)
     } else {
         if (mode == 0) SR3_GA(0, 0) else if (mode == 1) SR3_GA(1, 0) else SR3_GA(2, 0)

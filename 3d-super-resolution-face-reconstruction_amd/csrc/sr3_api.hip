@@ -50,6 +50,7 @@ struct Param {
     int cout = 0, cin = 0, ks = 0, cin_pad = 0;  // P_CONV
     float *dev = nullptr;                        // device storage (kernel layout)
     float *dev_split = nullptr;                  // P_CONV: split-f16 copy (prec 1), same size
+    float *dev_f8 = nullptr;                     // P_CONV 3x3: F8C copy of dev_split ("f16f8" mode; made on demand)
     float w_unscale = 1.0f;
     bool keep_host = false;                      // part of a fused (conv2 + res_conv) launch
     bool up_phase = false;                       // Upsample conv: stored as 4 sub-pixel phases x 2x2 taps
@@ -126,6 +127,10 @@ struct sr3_ctx {
     int c_max = 0;      // widest GroupNorm input
     uint64_t weight_bytes = 0;
     int prec = 0;       // 0 exact f32 MFMA, 1 split-f16 (f16x3) for the 3x3 / activated-input convs
+    // "f16f8" (sr3_set_precision(ctx, 2)): prec 1 with the two correction products of eligible convs on the fp8 matrix
+    // path (ConvParams::f8, conv_f8_supported). The f32 fallback of the range check leaves this flag alone.
+    bool f8corr = false;
+    bool f8_dirty = true;      // dev_f8 copies are stale (weights loaded / re-split since they were made)
     bool fused_dirty = true;   // fused bias / common weight scales need (re)building
     bool no_fused_stats = false;   // SR3_NO_FUSED_STATS=1: always run the statistics kernel (A/B testing)
     bool all_fused = false;        // every GroupNorm of the current workspace gets its statistics from a conv epilogue
@@ -172,8 +177,8 @@ struct sr3_ctx {
     StepArgs *h_ring = nullptr, *d_step = nullptr;
     uint64_t step_count = 0;
     // one p_sample step captured as a hipGraph (per precision); rebuilt when the workspace changes
-    hipGraphExec_t step_graph[2] = {nullptr, nullptr};
-    int graph_warm[2] = {0, 0};
+    hipGraphExec_t step_graph[3] = {nullptr, nullptr, nullptr};   // per arithmetic: f32, f16x3, f16f8
+    int graph_warm[3] = {0, 0, 0};
     bool no_graph = false;
 
     // profiling
@@ -437,6 +442,7 @@ struct ShapePool {
 };
 
 void drop_graphs(sr3_ctx *c);
+int prepare_f8(sr3_ctx *c);
 
 int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     if (c->arena && c->wB == B && c->wH == H && c->wW == W) return 0;
@@ -624,8 +630,10 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
 const TDesc kNone{};
 
 // GroupNorm statistics + apply (+Swish) (+concat) -> activated, zero-bordered conv input
+// f8: the consumer conv takes the F8C operand format (f8_conv() said so)
 void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act,
-                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc(), int in_split = 0) {
+                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc(), int in_split = 0, bool f8 = false) {
+    const int fmt = c->prec ? (f8 ? 2 : 1) : 0;
     c->pbegin(F_GN);
     const float *gamma = c->params[g.gamma].dev, *beta = c->params[g.beta].dev;
     // bytes the pass moves (read + write, 4 B per element each way): above ~200 MB the one-item-per-thread
@@ -640,16 +648,16 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
     if (sa.p && (!b.p || sb.p) && !c->no_fused_stats && (pass_bytes > fold_max || many_slices)) {
         launch_groupnorm_finalize(sa, a.C, sb, b.p ? b.C : 0, B, a.H * a.W, c->cfg.norm_groups, gamma, beta, 1e-5f,
                                   c->gscale, c->gshift, c->stream);
-        launch_gn_apply_rows(a, b, B, c->gscale, c->gshift, mode, c->prec, act, c->stream, raw, in_split, c->d_ovf);
+        launch_gn_apply_rows(a, b, B, c->gscale, c->gshift, mode, fmt, act, c->stream, raw, in_split, c->d_ovf);
     } else if (sa.p && (!b.p || sb.p) && !c->no_fused_stats) {
         // statistics came out of the producing convs' epilogues: finalize + apply are ONE launch
-        launch_gn_fold_apply(a, b, B, sa, sb, c->cfg.norm_groups, gamma, beta, 1e-5f, mode, c->prec, act, c->stream, raw,
+        launch_gn_fold_apply(a, b, B, sa, sb, c->cfg.norm_groups, gamma, beta, 1e-5f, mode, fmt, act, c->stream, raw,
                              in_split, c->d_ovf);
     } else {
         // fallback: streaming statistics kernel over the (fp32) tensors; its partials describe the
         // virtual concatenation as one source of a.C + b.C channels
         const StatsRef sp = launch_groupnorm_partials(a, b, B, c->gpart, c->stream);
-        launch_gn_fold_apply(a, b, B, sp, StatsRef(), c->cfg.norm_groups, gamma, beta, 1e-5f, mode, c->prec, act, c->stream,
+        launch_gn_fold_apply(a, b, B, sp, StatsRef(), c->cfg.norm_groups, gamma, beta, 1e-5f, mode, fmt, act, c->stream,
                              raw, in_split, c->d_ovf);
     }
     c->pend();
@@ -661,12 +669,13 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
               const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
               const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc(),
               bool out_f32 = true, bool resid_split = false, const float *w2_raw = nullptr, const GNRef *gnf = nullptr,
-              bool *gnf_done = nullptr) {
+              bool *gnf_done = nullptr, bool f8 = false) {
     ConvParams p;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
     p.prec = activated ? c->prec : 0;
     p.w = p.prec ? c->params[cv.w].dev_split : c->params[cv.w].dev;
+    if (f8 && p.prec) { p.f8 = 1; p.w = c->params[cv.w].dev_f8; }
     p.w_unscale = c->params[cv.w].w_unscale;
     p.bias = bias_override ? bias_override : (cv.b >= 0 ? c->params[cv.b].dev : nullptr);
     p.chan_bias = chan_bias; p.chan_bias_stride = c->cb_stride;
@@ -675,7 +684,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.out_f32 = (out_f32 || !p.out_split.p) ? 1 : 0;
     p.resid_split = resid_split ? 1 : 0;
     if (stats.p && !c->no_fused_stats) { p.stats = const_cast<double *>(stats.p); p.stats_slices = stats.slices; }
-    p.splits = conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
+    p.splits = p.f8 ? 1 : conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
     p.part = c->part;
     p.tile_cnt = c->tile_cnt;
     p.ovf = c->d_ovf;
@@ -687,7 +696,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
         p.w2 = w2_raw;
     }
     bool use_gnf = false;
-    if (gnf && p.prec == 1 && p.out_split.p && conv_gnf_supported(p, c->cfg.norm_groups)) {
+    if (gnf && p.prec == 1 && !p.f8 && p.out_split.p && conv_gnf_supported(p, c->cfg.norm_groups)) {
         // producer-side GroupNorm: the conv normalises its own output and writes swish(scale * h + shift) as out_split
         p.gnf_gamma = c->params[gnf->gamma].dev; p.gnf_beta = c->params[gnf->beta].dev;
         p.gnf_groups = c->cfg.norm_groups; p.gnf_eps = 1e-5f;
@@ -704,9 +713,14 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
         char tag[160];
         snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d fused1x1:%d prec%d%s", cv.ks, stride,
                  up2, out.H, out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, cv2 ? cv2->cin : 0, p.prec,
-                 use_gnf ? " +gn" : "");
+                 use_gnf ? " +gn" : (p.f8 ? " f8c" : ""));
         c->pend(2.0 * (double)B * out.H * out.W * cv.cout * ((double)(cv.ks * cv.ks) * cv.cin + (cv2 ? cv2->cin : 0)), tag);
     }
+}
+
+// "f16f8" mode: does this ResnetBlock conv (3x3, stride 1, activated input of cin channels) take the F8C operand format?
+bool f8_conv(const sr3_ctx *c, const ConvRef &cv, int B, int H, int W) {
+    return c->prec == 1 && c->f8corr && cv.ks == 3 && c->params[cv.w].dev_f8 != nullptr && conv_f8_supported(B, H, W, cv.cout, cv.cin);
 }
 
 TDesc unpadded(float *p, int C, int H, int W) {
@@ -727,26 +741,27 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     // the raw concatenation for the fused res_conv
     static const bool no_ident = getenv("SR3_NO_IDENT") && atoi(getenv("SR3_NO_IDENT"));   // A/B: epilogue gather
     const bool direct = rb.has_res && xr.p && (!skip.p || skr.p);
+    const bool f8a = f8_conv(c, rb.c1, B, h, w), f8b = f8_conv(c, rb.c2, B, h, w);
     run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, m.act1, sx, ss,
-               rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0));
+               rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0), f8a);
     // block1's conv + FeatureWiseAffine bias, then block2's GroupNorm + Swish: inside the conv where the producer-side
     // form applies (h1 then never exists: the conv writes act2), else as the apply pass over the fp32 h1
     bool gn2_done = false;
     run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1,
-             c->prec ? m.act2 : kNone, kNone, true, false, nullptr, c->prec && !c->no_fused_stats ? &rb.gn2 : nullptr, &gn2_done);
-    if (!gn2_done) run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef());
+             c->prec ? m.act2 : kNone, kNone, true, false, nullptr, c->prec && !c->no_fused_stats ? &rb.gn2 : nullptr, &gn2_done, f8a);
+    if (!gn2_done) run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef(), TDesc(), 0, f8b);
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
     // K-steps | + x as residual when the block keeps its width]
     const TDesc tw = rb.attn ? kNone : m.out_s;      // with attention the out-projection writes the module output
     if (rb.has_res)
         run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, direct ? xr : m.raw1, &rb.res,
-                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone, !out_so);
+                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone, !out_so, false, nullptr, nullptr, nullptr, f8b);
     else if (c->prec && rb.ident_w && xr.p && !no_ident)
         run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, xr, nullptr, nullptr, m.st_rb,
-                 tw, kNone, !out_so, false, rb.ident_w);
+                 tw, kNone, !out_so, false, rb.ident_w, nullptr, nullptr, f8b);
     else
         run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x_so ? xr : x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb,
-                 tw, kNone, !out_so, x_so);
+                 tw, kNone, !out_so, x_so, nullptr, nullptr, nullptr, f8b);
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
@@ -950,6 +965,24 @@ int prepare_fused(sr3_ctx *c) {
         HIP_OK(hipMemcpy(wr.dev_split, sp.data(), wr.dev_floats * sizeof(float), hipMemcpyHostToDevice));
     }
     c->fused_dirty = false;
+    c->f8_dirty = true;          // conv2 / res_conv tensors were re-split with a common scale
+    return 0;
+}
+
+// "f16f8" mode: F8C copies of the 3x3 conv weights (made on the device from the split-f16 copies; same byte size)
+int prepare_f8(sr3_ctx *c) {
+    if (!c->f8corr || !c->f8_dirty) return 0;
+    for (auto &p : c->params) {
+        if (p.kind != P_CONV || p.ks != 3 || p.up_phase || (p.cin_pad % 32) != 0 || !p.dev_split) continue;
+        if (!p.dev_f8) {
+            HIP_OK(hipMalloc(&p.dev_f8, p.dev_floats * sizeof(float)));
+            c->weight_bytes += p.dev_floats * sizeof(float);
+        }
+        launch_make_f8_weights(p.dev_split, p.dev_f8, p.dev_floats / 32, c->stream);
+    }
+    HIP_OK(hipGetLastError());
+    c->f8_dirty = false;
+    drop_graphs(c);              // (captured steps hold weight pointers; the copies may be new allocations)
     return 0;
 }
 
@@ -975,8 +1008,14 @@ int range_read(sr3_ctx *c) {
     return 1;
 }
 
-int warn_fallback(sr3_ctx *c, const char *what, const char *redo) {
-    char buf[512];
+// to_f16x3: only the fp8 operand range of the "f16f8" mode was exceeded and the plain split-f16 arithmetic held the rest
+int warn_fallback(sr3_ctx *c, const char *what, const char *redo, bool to_f16x3 = false) {
+    char buf[640];
+    if (to_f16x3)
+        snprintf(buf, sizeof buf, "%s: an activation exceeded the fp8 operand range (|v| > %g) of the f16f8 arithmetic; %s was "
+                 "recomputed with all three products on the f16 matrix path (f16x3). sr3_set_range_policy(ctx, 1) makes "
+                 "this an error instead; sr3_set_precision(ctx, 1) avoids the retry.", what, (double)SPLIT_F8_MAX, redo);
+    else
     snprintf(buf, sizeof buf, "%s: an activation exceeded the fp16 range (|v| > 65504) of the split-f16 format; %s was "
              "recomputed in the exact f32 arithmetic (the reference computes in fp32 and has no such limit). "
              "sr3_set_range_policy(ctx, 1) makes this an error instead; sr3_set_precision(ctx, 0) avoids the retry.",
@@ -998,11 +1037,12 @@ int check_ready(sr3_ctx *c) {
     HIP_OK(hipSetDevice(c->device));
     for (auto &p : c->params)
         if (!p.loaded) return fail("weight '%s' was never loaded (sr3_load_weight)", p.name.c_str());
-    return prepare_fused(c);
+    if (prepare_fused(c)) return -1;
+    return prepare_f8(c);
 }
 
 void drop_graphs(sr3_ctx *c) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (c->step_graph[i]) (void)hipGraphExecDestroy(c->step_graph[i]);
         c->step_graph[i] = nullptr;
         c->graph_warm[i] = 0;
@@ -1047,7 +1087,7 @@ int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
     sa.seed = c->seed; sa.image_offset = c->image_offset;
     HIP_OK(hipMemcpyAsync(c->d_step, &sa, sizeof(StepArgs), hipMemcpyHostToDevice, c->stream));
 
-    const int g = c->prec;
+    const int g = c->prec ? (c->f8corr ? 2 : 1) : 0;
     if (c->prof || c->no_graph) {
         enqueue_step(c);
         return 0;
@@ -1129,6 +1169,7 @@ void sr3_destroy(sr3_ctx *c) {
     for (auto &p : c->params) {
         if (p.owns && p.dev) (void)hipFree(p.dev);
         if (p.dev_split) (void)hipFree(p.dev_split);
+        if (p.dev_f8) (void)hipFree(p.dev_f8);
     }
     if (c->final_wq) (void)hipFree(c->final_wq);
     if (c->ci_w) (void)hipFree(c->ci_w);
@@ -1181,10 +1222,14 @@ int sr3_stream_wait_for_ctx(sr3_ctx *c, void *other_stream) {
 
 int sr3_set_precision(sr3_ctx *c, int prec) {
     if (!c) return fail("null context");
-    if (prec != 0 && prec != 1) return fail("precision %d unknown (0 = f32 exact, 1 = split-f16)", prec);
-    c->prec = prec;
+    if (prec < 0 || prec > 2)
+        return fail("precision %d unknown (0 = f32 exact, 1 = split-f16, 2 = split-f16 with fp8 correction products)", prec);
+    c->prec = prec ? 1 : 0;
+    c->f8corr = prec == 2;
     return 0;
 }
+
+int sr3_conv_f8_supported(int B, int H, int W, int Cout, int Cin) { return conv_f8_supported(B, H, W, Cout, Cin) ? 1 : 0; }
 
 int sr3_synchronize(sr3_ctx *c) {
     if (!c) return fail("null context");
@@ -1255,6 +1300,7 @@ int sr3_load_weight(sr3_ctx *c, const char *name, const float *host, const int64
         }
         p.loaded = true;
         c->fused_dirty = true;
+        c->f8_dirty = true;
         drop_graphs(c);     // captured steps hold the old w_unscale scalars in their kernel arguments
         return 0;
     }
@@ -1297,7 +1343,16 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     if (c->strict_range) return range_check(c, "sr3_unet_forward");
     const int r = range_read(c);
     if (r <= 0) return r;
-    // out of range: the caller still owns x and noise_level, so the forward is simply evaluated again in f32
+    // out of range: the caller still owns x and noise_level, so the forward is simply evaluated again — f16f8 first
+    // without the fp8 products (their operand range is the narrower one), then in f32
+    if (c->f8corr) {
+        c->f8corr = false;
+        const int rc8 = unet_forward_once(c, x_dev, noise_level_dev, B, H, W, out_dev);
+        const int r8 = rc8 ? -1 : range_read(c);
+        c->f8corr = true;
+        if (r8 < 0) return -1;
+        if (r8 == 0) return warn_fallback(c, "sr3_unet_forward", "the forward pass", true);
+    }
     c->prec = 0;
     const int rc = unet_forward_once(c, x_dev, noise_level_dev, B, H, W, out_dev);
     c->prec = 1;
@@ -1402,19 +1457,23 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
         c->ckpt_floats = slab;
     }
     auto save = [&]() { launch_nhwc_to_nchw(c->x0, nc, B, C, c->ckpt, c->stream); };
-    // back to the last clean boundary, exact f32 from here on (the mode is restored before the call returns)
+    // back to the last clean boundary, one arithmetic down from here on: f16f8 -> f16x3 (the fp8 operands have the
+    // narrower range; the guard stays on) -> exact f32 (the mode is restored before the call returns)
+    const bool f8_was = c->f8corr;
     auto fall_back = [&]() {
         launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
         if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
-        c->prec = 0;
+        if (c->f8corr) c->f8corr = false;
+        else c->prec = 0;
     };
     int t_ck = T - 1, f_ck = 0;          // the checkpoint holds the state BEFORE step t_ck; f_ck frames were written by then
-    bool fell_back = false;
+    bool fell_back = false;              // exact f32 from here on: no more range checks
+    bool any_fallback = false;
     int rc = 0;
     if (guard) {
         const int r = range_read(c);     // (the initial state / its packed copy)
         if (r < 0) return -1;
-        if (r > 0) { c->prec = 0; fell_back = true; }
+        if (r > 0) { c->prec = 0; fell_back = any_fallback = true; }
         else save();
     }
     int f = 0;
@@ -1423,7 +1482,7 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
             const int r = range_read(c);
             if (r < 0) { rc = -1; break; }
             if (r > 0) {
-                fall_back(); fell_back = true;
+                fall_back(); fell_back = c->prec == 0; any_fallback = true;
                 t = t_ck; f = f_ck;
             } else {
                 save();
@@ -1438,7 +1497,7 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
             const int r = range_read(c);
             if (r < 0) { rc = -1; break; }
             if (r > 0) {
-                fall_back(); fell_back = true;
+                fall_back(); fell_back = c->prec == 0; any_fallback = true;
                 t = t_ck + 1; f = f_ck;             // (the loop's --t resumes at t_ck)
             }
         }
@@ -1449,14 +1508,15 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
             launch_nhwc_to_nchw(c->x0, nc, c->wB, C, out_dev, c->stream);
             c->pend();
             if (hipGetLastError() != hipSuccess) rc = fail("sr3_sample: launch failed");
-            if (fell_back && rc == 0 && hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream) != hipSuccess) rc = fail("hipMemsetAsync failed");
+            if (any_fallback && rc == 0 && hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream) != hipSuccess) rc = fail("hipMemsetAsync failed");
         } else {
             rc = sr3_sample_end(c, out_dev);
         }
     }
-    if (fell_back) c->prec = 1;
+    const bool to_f16x3 = any_fallback && !fell_back;
+    if (any_fallback) { c->prec = 1; c->f8corr = f8_was; }
     if (rc) return rc;
-    return fell_back ? warn_fallback(c, "sr3_sample", "the rest of the loop from the last in-range checkpoint") : 0;
+    return any_fallback ? warn_fallback(c, "sr3_sample", "the rest of the loop from the last in-range checkpoint", to_f16x3) : 0;
 }
 
 int sr3_set_range_policy(sr3_ctx *c, int strict) {
@@ -1544,6 +1604,16 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     float *dw = nullptr, *db = nullptr, *act = nullptr;
     HIP_OK(hipMalloc(&dw, packed.size() * sizeof(float)));
     HIP_OK(hipMemcpy(dw, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    // "f16f8" mode: the conv runs as the engine would run it for this shape (F8C operands where conv_f8_supported)
+    const bool f8 = c->prec == 1 && c->f8corr && ks == 3 && stride == 1 && !up2 && conv_f8_supported(B, Hin, Win, Cout, Cin);
+    if (f8) {
+        float *dw8 = nullptr;
+        HIP_OK(hipMalloc(&dw8, packed.size() * sizeof(float)));
+        launch_make_f8_weights(dw, dw8, packed.size() / 32, c->stream);
+        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipFree(dw));
+        dw = dw8;
+    }
     if (bias_host) {
         HIP_OK(hipMalloc(&db, (size_t)Cout * sizeof(float)));
         HIP_OK(hipMemcpy(db, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
@@ -1556,14 +1626,14 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     const TDesc i0 = unpadded(const_cast<float *>(in0_dev), C0, Hin, Win);
     const TDesc i1 = in1_dev ? unpadded(const_cast<float *>(in1_dev), C1, Hin, Win) : kNone;
     if (range_reset(c)) return -1;
-    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, c->prec, a, c->stream,
+    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, f8 ? 2 : c->prec, a, c->stream,
                     TDesc(), 0, c->d_ovf);
     const int pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
     ConvParams p;
     p.in0 = a; p.B = B;
     p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1;
     p.ks = ks; p.stride = stride; p.up2 = up2;
-    p.prec = c->prec; p.w_unscale = w_unscale;
+    p.prec = c->prec; p.w_unscale = w_unscale; p.f8 = f8 ? 1 : 0;
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
     p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
     if (resid_dev) p.resid = unpadded(const_cast<float *>(resid_dev), Cout, p.Hout, p.Wout);
@@ -1624,6 +1694,8 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     p.in0 = act; p.B = B; p.Hout = Ho; p.Wout = Wo;
     p.ks = ks; p.stride = stride; p.up2 = up2; p.w = w; p.bias = bias;
     p.prec = c->prec;
+    const bool f8 = c->prec == 1 && c->f8corr && ks == 3 && stride == 1 && !up2 && conv_f8_supported(B, Hin, Win, Cout, Cin);
+    p.f8 = f8 ? 1 : 0;       // (timing: the operand bytes are random either way)
     p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
     if (with_resid) p.resid = res;
     p.out = out;
@@ -1646,7 +1718,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     HIP_OK(hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) go();
     HIP_OK(hipEventRecord(e1, c->stream));
-    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, c->prec, act, c->stream);
+    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, f8 ? 2 : c->prec, act, c->stream);
     HIP_OK(hipEventRecord(e2, c->stream));
     HIP_OK(hipEventSynchronize(e2));
     float ms = 0.f;

@@ -69,6 +69,13 @@ struct ConvParams {
     //         hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; weights are
     //         pre-scaled by 2^k (w_unscale = 2^-k is applied to the accumulator in the epilogue).
     int prec = 0;
+    // f8 = 1 (prec 1 only; "f16f8" mode, conv_f8_supported() tells for which shapes): in0 / in1 and w are in the F8C
+    // variant of the split format — per 32-channel chunk 32 hi halfs | 32 x e4m3(lo * 2^SR3_F8_XL) | 32 x e4m3(hi * 2^SR3_F8_XH)
+    // for activations, 32 hi halfs | 32 x e4m3(hi * 2^SR3_F8_WH) | 32 x e4m3(lo * 2^SR3_F8_WL) for weights — and the two
+    // correction products xl*wh + xh*wl run as ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile and K-step (half the
+    // cycles of the four f16 MFMAs they replace; ~6e-5 instead of ~4e-6 from the reference over a sampler run).
+    // in2 / in2b / w2 (fused 1x1 term) stay in the plain split format.
+    int f8 = 0;
     float w_unscale = 1.0f;
     // split-K for small problems (few tiles, deep K): `splits` blocks share one output tile, each
     // reducing a contiguous range of 32-channel chunks into part[split][M][Cout]; a second kernel
@@ -127,6 +134,16 @@ __device__ __forceinline__ unsigned split_pair_word(float v, unsigned selector, 
     return __builtin_amdgcn_perm(oth, own, selector);
 }
 __device__ __forceinline__ bool split_range_overflow(unsigned range) { return range == 0x7C00u; }
+// F8C operand scaling (powers of two; activations beyond e4m3's 448 raise the range flag). The CPU emulation of these
+// formats (tests/emulate_operand_formats.py) gives the same sampler error for activation exponents 0, 2 and 4.
+constexpr int SR3_F8_XH = 0, SR3_F8_XL = 11;      // xh8 = e4m3(xh), xl8 = e4m3(xl * 2048)   (|xl| <= 2^-11 |xh|: <= 256 at the limit)
+constexpr int SR3_F8_WH = -3, SR3_F8_WL = 9;      // weights are pre-scaled into [1024, 2048): wh8 < 256, |wl| <= 0.5 -> wl8 <= 256
+constexpr float SPLIT_F8_MAX = 448.0f;
+// true when launch_conv runs this 3x3 / stride-1 split-f16 conv with the fp8 correction products if ConvParams::f8 is set
+// (the caller then writes the conv's input with split format 2 and passes the F8C weights)
+bool conv_f8_supported(int B, int H, int W, int Cout, int Cin);
+// split weights [chunks][32 hi | 32 lo] -> F8C weights [chunks][32 hi | 32 wh8 | 32 wl8] (device to device)
+void launch_make_f8_weights(const float *split, float *dst, size_t chunks, hipStream_t s);
 void launch_conv(const ConvParams &p, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
 // parity (py, px) see only a 2x2 window of the low-resolution input, with the 3x3 taps that land
@@ -172,8 +189,9 @@ void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, i
                                const float *gamma, const float *beta, float eps, float *scale, float *shift,
                                hipStream_t s);
 // out[n,y,x,:] = act(concat(in0,in1)[n,y,x,:] * scale[n,:] + shift[n,:]); mode 0 copy, 1 affine,
-// 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only. split != 0 stores every
-// 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format).
+// 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only. split = 1 stores every
+// 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format), split = 2 as
+// 32 hi halfs | 32 x e4m3(lo * 2^SR3_F8_XL) | 32 x e4m3(hi * 2^SR3_F8_XH) (ConvParams::f8; `raw` stays format 1).
 // raw (optional, p != nullptr): additionally stores the un-normalised concatenation in the same
 // format (the input of a fused res_conv).
 // in_split: bit 0 / bit 1 = in0 / in1 is itself stored in the split-f16 format (split-only tensors)

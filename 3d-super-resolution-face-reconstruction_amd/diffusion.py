@@ -179,7 +179,8 @@ class GaussianDiffusion(nn.Module):
             # the step API cannot replay inside the library (the caller owns the noise); this facade still holds
             # x, cond and noise, so an out-of-range split-f16 step is evaluated again in exact f32 — the
             # reference computes in fp32 and has no range limit (unet.py:235-265)
-            if "fp16 range" not in str(e) or getattr(eng, "precision", "f32") != "f16x3" or self.denoise_fn.strict_range:
+            prev = getattr(eng, "precision", "f32")
+            if "fp16 range" not in str(e) or prev == "f32" or self.denoise_fn.strict_range:
                 raise
             import warnings
             from ._lib import Sr3RangeWarning
@@ -187,7 +188,7 @@ class GaussianDiffusion(nn.Module):
             try:
                 one_step()
             finally:
-                eng.set_precision("f16x3")
+                eng.set_precision(prev)
             warnings.warn(Sr3RangeWarning(f"p_sample(t={int(t)}) recomputed in exact f32: {e}"), stacklevel=2)
         self.denoise_fn.finish()
         return out

@@ -99,10 +99,15 @@ class Engine:
     def set_stream(self, stream_handle: Optional[int]):
         _lib.check(self.lib.sr3_set_stream(self.ctx, stream_handle or None))
 
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16f8": 2}
+
+    def conv_f8_supported(self, B: int, H: int, W: int, Cout: int, Cin: int) -> bool:
+        """Does the 'f16f8' mode run a 3x3 / stride-1 conv of this shape with fp8 correction products?"""
+        return bool(self.lib.sr3_conv_f8_supported(B, H, W, Cout, Cin))
 
     def set_precision(self, name: str):
-        """'f32': exact fp32 MFMA (default). 'f16x3': split-f16 operands, fp32-equivalent accuracy."""
+        """'f32': exact fp32 MFMA (default). 'f16x3': split-f16 operands, fp32-equivalent accuracy. 'f16f8': f16x3 with
+        the correction products of the MFMA-bound convs on the fp8 matrix path (~6e-5 from the reference, faster)."""
         _lib.check(self.lib.sr3_set_precision(self.ctx, self.PRECISIONS[name]))
         self.precision = name
 

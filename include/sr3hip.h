@@ -73,8 +73,18 @@ int sr3_stream_wait_for_ctx(sr3_ctx *ctx, void *other_stream);
 /* Arithmetic of the convolutions: 0 = exact f32 on v_mfma_f32_32x32x2_f32 (default; bit-faithful
  * fp32 products), 1 = split-f16 ("f16x3"): operands stored as hi + lo halfs, three
  * v_mfma_f32_32x32x16_f16 per product with fp32 accumulation — fp32-equivalent accuracy (error of
- * the same size as fp32 accumulation itself) at ~5x the matrix rate. */
+ * the same size as fp32 accumulation itself) at ~5x the matrix rate.
+ * 2 = "f16f8": mode 1 with the two CORRECTION products (x_lo*w_hi + x_hi*w_lo) of the MFMA-bound 3x3 convs (32x32- and
+ * 16x16-pixel levels at full batch) on the fp8 matrix path: operands additionally stored as OCP e4m3 with power-of-two
+ * scales, one v_mfma_scale_f32_32x32x64_f8f6f4 instead of four f16 MFMAs per 32x32 tile and K-step. Correction terms
+ * carry 2^-11 of the product, so 3 mantissa bits there cost ~2^-16 relative: 5e-5..7e-5 from the reference over whole
+ * sampler runs (bar 1e-3) instead of 4e-6 if EVERY conv took that path (CPU emulation); measured with the eligible
+ * layers: 1e-5. Activations beyond 448 (e4m3) in those layers raise the range flag, as 65504 does in mode 1; the default
+ * policy then repeats the work in mode 1 first, in f32 if that overflows too. No reference counterpart (unet.py
+ * computes in fp32). */
 int sr3_set_precision(sr3_ctx *ctx, int prec);
+/* 1 when mode 2 runs a 3x3 / stride-1 conv of this shape with fp8 correction products, else 0 (tests, tools) */
+int sr3_conv_f8_supported(int B, int H, int W, int Cout, int Cin);
 
 /* ---- weights: reference state_dict names and layouts ------------------------------------- */
 
