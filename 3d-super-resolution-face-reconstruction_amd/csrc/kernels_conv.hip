@@ -1705,14 +1705,10 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
         rplain[mi] = wm * WM + mi * 32 + li;
         rhalo[mi] = rplain[mi] + HALO * (rplain[mi] / SEG);
     }
-    // second halves of the rows (lo halfs, or fp8 operands in F8C K-steps): both 16-wide K blocks of a K-step side by side
-    // in ONE 8-register tuple, so that the fp8 MFMA takes it as it is and the f16 MFMAs take its halves
+    // second halves of the rows (lo halfs, or fp8 operands in F8C K-steps): the two 16-byte reads of a K-step are
+    // concatenated into the fp8 MFMA's 8-register operand (the compiler loads them into adjacent registers: no moves)
     h16x8 ah[2][MI], bh[2][NI];
-    i32x8 al8[MI], bl8[NI];
-    auto half_of = [](const i32x8 &v, auto set_c) {
-        constexpr int S = decltype(set_c)::value;
-        return __builtin_bit_cast(h16x8, __builtin_shufflevector(v, v, 4 * S, 4 * S + 1, 4 * S + 2, 4 * S + 3));
-    };
+    i32x4 alq[2][MI], blq[2][NI];
     // fragment reads of K-step KT, 16-wide K block SB into register set SET
 #define SR3_HREAD(SET, KT, SB)                                                                     \
     {                                                                                              \
@@ -1731,14 +1727,12 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             const int R_ = halo_ ? rhalo[mi] + dx_ : rplain[mi];                                   \
             const int sw_ = (R_ >> 1) & 7;                                                         \
             ah[SET][mi] = *reinterpret_cast<const h16x8 *>(Ab_ + R_ * ROWF + (((2 * (SB) + lh) ^ sw_) & 7) * 4);     \
-            const i32x4 t_ = *reinterpret_cast<const i32x4 *>(Ab_ + R_ * ROWF + ((c2_ ^ sw_) & 7) * 4); \
-            al8[mi][4 * (SET)] = t_[0]; al8[mi][4 * (SET) + 1] = t_[1]; al8[mi][4 * (SET) + 2] = t_[2]; al8[mi][4 * (SET) + 3] = t_[3]; \
+            alq[SET][mi] = *reinterpret_cast<const i32x4 *>(Ab_ + R_ * ROWF + ((c2_ ^ sw_) & 7) * 4); \
         }                                                                                          \
         const int lob_ = ((c2_ ^ swzB) & 7) * 4;                                                   \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                        \
             bh[SET][ni] = *reinterpret_cast<const h16x8 *>(Bb_ + ni * 32 * ROWF + hoffB[SB]);      \
-            const i32x4 t_ = *reinterpret_cast<const i32x4 *>(Bb_ + ni * 32 * ROWF + lob_);        \
-            bl8[ni][4 * (SET)] = t_[0]; bl8[ni][4 * (SET) + 1] = t_[1]; bl8[ni][4 * (SET) + 2] = t_[2]; bl8[ni][4 * (SET) + 3] = t_[3]; \
+            blq[SET][ni] = *reinterpret_cast<const i32x4 *>(Bb_ + ni * 32 * ROWF + lob_);          \
         }                                                                                          \
     }
     // F8C (ConvParams::f8): in the halo K-steps the second half of a row holds fp8 operands — (xl8 | xh8) for A, (wh8 | wl8)
@@ -1754,13 +1748,15 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             if ((SET) == 0) {                                                                      \
                 _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                  \
                 _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                  \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al8[mi], bl8[ni], acc[mi][ni], 0, 0, 0, f8_scale_a, 0, f8_scale_b); \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                 \
+                        __builtin_shufflevector(alq[0][mi], alq[1][mi], 0, 1, 2, 3, 4, 5, 6, 7),           \
+                        __builtin_shufflevector(blq[0][ni], blq[1][ni], 0, 1, 2, 3, 4, 5, 6, 7), acc[mi][ni], 0, 0, 0, f8_scale_a, 0, f8_scale_b); \
             }                                                                                      \
         } else {                                                                                   \
             _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                      \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                    \
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(half_of(al8[mi], std::integral_constant<int, (SET)>{}), bh[SET][ni], acc[mi][ni], 0, 0, 0); \
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], half_of(bl8[ni], std::integral_constant<int, (SET)>{}), acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, alq[SET][mi]), bh[SET][ni], acc[mi][ni], 0, 0, 0); \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], __builtin_bit_cast(h16x8, blq[SET][ni]), acc[mi][ni], 0, 0, 0); \
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[SET][mi], bh[SET][ni], acc[mi][ni], 0, 0, 0); \
             }                                                                                      \
         }                                                                                          \

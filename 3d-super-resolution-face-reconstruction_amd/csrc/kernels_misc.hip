@@ -255,12 +255,12 @@ __device__ __forceinline__ float swish_fast(float x) {
     return x * __frcp_rn(1.0f + __expf(-x));
 }
 
-// e4m3 (OCP) pair conversion: v_cvt_pk_fp8_f32 into the low / high half of a word; inputs clamped to the format's
-// finite range (the callers raise the range flag for values that would saturate)
+// e4m3 (OCP) pair conversion: v_cvt_pk_fp8_f32 into the low / high half of a word. The instruction does not saturate
+// (|v| > 448 becomes NaN); no clamp here: the callers raise the range flag for exactly those values (|x| > SPLIT_F8_MAX,
+// which also bounds x_lo * 2^11 by 256) and the flagged call's results are discarded and recomputed (or the call fails).
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
-    auto cl = [](float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); };
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
 }
 
@@ -288,8 +288,9 @@ __device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8], f
             uint2 l8, h8;
             l8.x = pack4_e4m3(lof[0] * SL, lof[1] * SL, lof[2] * SL, lof[3] * SL);
             l8.y = pack4_e4m3(lof[4] * SL, lof[5] * SL, lof[6] * SL, lof[7] * SL);
-            h8.x = pack4_e4m3((float)hi[0] * SH, (float)hi[1] * SH, (float)hi[2] * SH, (float)hi[3] * SH);
-            h8.y = pack4_e4m3((float)hi[4] * SH, (float)hi[5] * SH, (float)hi[6] * SH, (float)hi[7] * SH);
+            // (the fp32 value itself instead of its fp16 rounding: the same e4m3 number except at rounding ties)
+            h8.x = pack4_e4m3(f[0] * SH, f[1] * SH, f[2] * SH, f[3] * SH);
+            h8.y = pack4_e4m3(f[4] * SH, f[5] * SH, f[6] * SH, f[7] * SH);
             *reinterpret_cast<uint2 *>(b8) = l8;
             *reinterpret_cast<uint2 *>(b8 + 32) = h8;
         } else {

@@ -83,10 +83,12 @@ class UNet(nn.Module):
             _register(self, name, nn.Parameter(t))
         self._engine: Optional[Engine] = None
         self._synced = {}
-        # conv arithmetic: "f16x3" = split-f16 operands with fp32 accumulation (fp32-equivalent
-        # accuracy, ~3x faster; default) or "f32" = exact fp32 MFMA. Both pass the 1e-3 parity bar
-        # against the reference with ~1e-6 (tests/test_gpu_sampler.py).
-        self.precision = os.environ.get("SR3_PRECISION", "f16x3")
+        # conv arithmetic: "f16x3" = split-f16 operands with fp32 accumulation (fp32-equivalent accuracy, ~2.6x
+        # faster than "f32" = exact fp32 MFMA); "f16f8" (default) = f16x3 with the two correction products of the
+        # MFMA-bound convs (32x32- and 16x16-pixel levels at full batch) on the fp8 matrix path, another 2-3 %
+        # faster. All pass the 1e-3 parity bar against the reference: ~4e-6 (f32, f16x3) and ~2e-5 (f16f8) over the
+        # 1000-step headline run (tests/test_gpu_round3.py, tests/test_gpu_f16f8.py).
+        self.precision = os.environ.get("SR3_PRECISION", "f16f8")
         # split-f16 range policy: False (default) = a call whose activations leave the fp16 range is finished in
         # exact f32 with an `Sr3RangeWarning`; True = it raises `Sr3Error` (sr3_set_range_policy)
         self.strict_range = bool(int(os.environ.get("SR3_STRICT_RANGE", "0")))

@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--lres", type=int, default=16)
     ap.add_argument("--T", type=int, default=1000, help="diffusion steps per image (BASELINE configs[1]: 1000)")
     ap.add_argument("--image-size", type=int, default=224, help="UNet image_size key: 224 = yml-literal, 128 = 6 attention modules")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16f8"],
+    ap.add_argument("--precision", default="f16f8", choices=["f32", "f16x3", "f16f8"],
                     help="conv arithmetic: exact f32 MFMA, or split-f16 (fp32-equivalent accuracy, default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary measurement of the other precision")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -287,22 +287,27 @@ def main():
         }
 
     alt = None
+    alts = {}
     if rank == 0 and not args.no_alt:
-        other = "f32" if args.precision != "f32" else "f16x3"
-        eng.set_precision(other)
-        t_a = run_steps(max(1, W), t_next)
-        torch.cuda.synchronize()
-        ta0 = time.perf_counter()
-        t_a = run_steps(K, t_a)
-        torch.cuda.synchronize()
-        sa = (time.perf_counter() - ta0) / K
-        eng.profile_reset(); eng.profile_enable(True)
-        run_steps(min(K, 5), t_a)
-        pa = eng.profile_get()["conv_igemm"]
-        eng.profile_enable(False)
-        alt = {"precision": other, "ms_per_step": sa * 1e3, "img_per_s_1gpu": B / (T * sa),
-               "conv_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] else 0.0,
-               "conv_frac_of_peak": (pa["flops"] / (pa["ms"] * 1e-3) / 1e12) / PEAK_TFLOPS[other] if pa["ms"] else 0.0}
+        # the other arithmetic modes of the same library on the same box: exact f32 always; f16x3 next to f16f8
+        others = ["f32"] if args.precision == "f16x3" else (["f32", "f16x3"] if args.precision == "f16f8" else ["f16x3", "f16f8"])
+        t_a = t_next
+        for other in others:
+            eng.set_precision(other)
+            t_a = run_steps(max(1, W), t_a)
+            torch.cuda.synchronize()
+            ta0 = time.perf_counter()
+            t_a = run_steps(K, t_a)
+            torch.cuda.synchronize()
+            sa = (time.perf_counter() - ta0) / K
+            eng.profile_reset(); eng.profile_enable(True)
+            run_steps(min(K, 5), t_a)
+            pa = eng.profile_get()["conv_igemm"]
+            eng.profile_enable(False)
+            alts[other] = {"precision": other, "ms_per_step": sa * 1e3, "img_per_s_1gpu": B / (T * sa),
+                           "conv_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] else 0.0,
+                           "conv_frac_of_peak": (pa["flops"] / (pa["ms"] * 1e-3) / 1e12) / PEAK_TFLOPS[other] if pa["ms"] else 0.0}
+        alt = alts[others[0]]
         eng.set_precision(args.precision)
     if rank == 0:
         res = {
@@ -319,6 +324,7 @@ def main():
                                       (" (SR3_FORCE_COLLECTIVE: world-size-1 RCCL all-gather executed)" if collective and world == 1 else "")},
             "roofline": roof,
             "alt_precision": alt,
+            "alt_precisions": alts,
         }
         if world == 1 and not args.no_full_loop:
             res["full_loop"] = full_loop(eng, torch, B, r, T, cond, sec_per_step)

@@ -88,7 +88,7 @@ def test_real_sampler_sharded_over_ranks(world, n, which):
         assert p.exitcode == 0
     covered = []
     for rank, out, (a, b), prec in res:
-        assert prec == "f16x3"
+        assert prec == "f16f8"      # the facade default (the fp8 path itself needs B >= 32: not taken at these sizes)
         assert out.shape == want.shape
         err = np.abs(out - want).max()
         assert err <= 2e-5, (rank, err)                 # every rank holds the full gathered batch

@@ -197,6 +197,31 @@ def test_fp8_range_falls_back_to_f16x3_first():
     e.close()
 
 
+def test_headline_T1000_golden_replicated_f16f8():
+    """The benchmarked configuration pinned to the reference over its FULL horizon with the fp8 path active: the
+    reference-made fixture tests/golden/sampler_cfg2_16_128_T1000.npz (16 -> 128, yml-literal UNet, T = 1000, B = 1;
+    diffusion.py:189-215) replicated to B = 64 — every replica takes the same injected noise (12.6 GB of it) — and each
+    of the 64 results held to the reference's frames and final image. Bar 1e-3."""
+    g = load_golden("sampler_cfg2_16_128_T1000.npz")
+    m = g["meta"]
+    cfg = cfg_from_meta(m)
+    r, T, st = m["r"], m["schedule"]["n_timestep"], m["frame_stride"]
+    assert (m["B"], r, T) == (1, 128, 1000)
+    B = 64
+    e = _engine(cfg, synth.synth_state_dict(cfg, m["seed"]), "f16f8", m["schedule"])
+    noise = np.broadcast_to(synth.synth_noise(T, 1, 3, r, r, m["seed"]), (T, B, 3, r, r))
+    cond = np.tile(g["cond"], (B, 1, 1, 1))
+    final, frames = e.sample_np(cond, noise=np.ascontiguousarray(noise), frames=True)
+    del noise
+    assert e.fallback_calls() == 0
+    e.close()
+    err = np.abs(frames[..., ::st, ::st] - g["frames_sub"]).reshape(10, -1).max(1)       # (frames_sub broadcasts over B)
+    e_fin = np.abs(final - g["final"]).max()
+    print(f"cfg2 16->128 T=1000 x{B} [f16f8]: per-frame max abs err {np.array2string(err, precision=2)}; final {e_fin:.2e}")
+    assert err.max() <= BAR and e_fin <= BAR
+    np.testing.assert_array_equal(final[0], final[B - 1])
+
+
 def test_headline_loop_f16f8_vs_f32():
     """The benchmarked configuration (16 -> 128, B = 64, T = 1000, device Philox noise): the whole loop in f16f8 against
     the exact-f32 mode of the same library — the same check tests/test_gpu_round2.py makes for f16x3 (the

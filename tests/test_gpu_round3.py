@@ -234,7 +234,7 @@ def test_facade_finishes_overflowing_calls():
     netG = P.define_G(opt).cuda()
     netG.load_state_dict({"denoise_fn." + k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     netG.set_new_noise_schedule(sched, [0])
-    assert netG.denoise_fn.precision == "f16x3"
+    assert netG.denoise_fn.precision == "f16f8"
     cond, noise = synth.synth_cond(2, 16, 8, 2), synth.synth_noise(8, 2, 3, 16, 16, 2)
     want, _ = oracle.p_sample_loop(sd, cfg, oracle.noise_schedule(sched), cond, noise)
     with warnings.catch_warnings(record=True) as rec:

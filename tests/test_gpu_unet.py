@@ -89,7 +89,7 @@ def test_torch_facade_state_dict_and_forward():
     with pytest.raises(pkg("_lib").Sr3Error, match="no CPU fallback"):
         netG.denoise_fn(torch.from_numpy(g["x"]), torch.from_numpy(g["noise_level"]))
     netG = netG.cuda()
-    assert netG.denoise_fn.precision == "f16x3"
+    assert netG.denoise_fn.precision == "f16f8"
     sd = {"denoise_fn." + k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, g["meta"]["seed"]).items()}
     res = netG.load_state_dict(sd, strict=False)
     assert not res.missing_keys and not res.unexpected_keys

@@ -1,11 +1,13 @@
 #!/bin/bash
-# One-call evidence collection for a round (run through gpurun): kernel stats + PMC passes in both precisions,
+# One-call evidence collection for a round (run through gpurun): kernel stats + PMC passes in the three arithmetic modes,
 # the per-shape conv table, the default bench line with the full loop, every BASELINE config on one GPU, and the
 # config-3 kernel stats. Outputs under gpurun_out/; summarise with tools/pmc_summary.py and copy into profiles/.
 set -e
+bash tools/profile_round.sh f16f8 > gpurun_out/pr_f16f8.log 2>&1
 bash tools/profile_round.sh f16x3 > gpurun_out/pr_f16x3.log 2>&1
 bash tools/profile_round.sh f32 > gpurun_out/pr_f32.log 2>&1
-python tools/step_profile.py --batch 64 --steps 20 --csv gpurun_out/conv_shapes_f16x3.csv > gpurun_out/sp64.txt 2>&1
+python tools/step_profile.py --batch 64 --steps 20 --precision f16f8 --csv gpurun_out/conv_shapes_f16f8.csv > gpurun_out/sp64.txt 2>&1
+python tools/step_profile.py --batch 64 --steps 20 --precision f16x3 --csv gpurun_out/conv_shapes_f16x3.csv >> gpurun_out/sp64.txt 2>&1
 python bench.py > gpurun_out/bench_full.log 2>&1
 : > gpurun_out/configs.txt
 run_cfg() { echo "== bench.py $*" >> gpurun_out/configs.txt; python bench.py "$@" --no-alt --no-cpu-baseline 2>/dev/null | tail -n 1 >> gpurun_out/configs.txt; }

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--lres", type=int, default=16)
     ap.add_argument("--image-size", type=int, default=224)
-    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--precision", default="f16f8")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--csv", default="")
