@@ -18,9 +18,11 @@ images at the end of the timed region.
 The JSON line also carries
   roofline     the conv implicit-GEMM kernel family: algorithmic FLOPs / HIP-event time per launch
                against the dense MFMA peak of the mode's instruction — 2500 TFLOP/s (f16 MFMA) in the
-               default split-f16 mode, 157.3 TFLOP/s (f32-input MFMA) with --precision f32 — plus
-               `executed_frac`: the MFMA work actually issued (3 MFMA MACs per product in split-f16,
-               16/36 of the MACs on the sub-pixel Upsample convs) over the same peak
+               split-f16 modes (the default f16f8 is priced against the f16 peak too, although a third of its
+               conv work issues half of its MFMA cycles on the fp8 path), 157.3 TFLOP/s (f32-input MFMA) with
+               --precision f32 — plus `executed_frac`: the MFMA work issued in f16x3 accounting (3 MFMA MACs per
+               product, 16/36 of the MACs on the sub-pixel Upsample convs) over the same peak
+  alt_precisions  the other arithmetic modes of the same library measured in the same run (exact f32; f16x3)
   full_loop    ONE whole sr3_sample call (T steps, intermediate frames recorded) timed end to end:
                the sustained rate next to the K-step figure
   cpu_baseline oracle/sr3_oracle_aten.py (the build's restatement on torch's CPU operators — what the
