@@ -138,6 +138,28 @@ def test_unet_forward_golden_replicated_f16f8(name):
     np.testing.assert_array_equal(eps8[0], eps8[B - 1])      # replicas are bit-identical
 
 
+@pytest.mark.parametrize("B", [33, 63])
+def test_unet_forward_ragged_batches_f16f8(B):
+    """Shards that are not multiples of anything: at B = 33 / 63 only the 32x32 level has enough 128x128 tiles for the
+    fp8 path (the 16x16 level stays f16x3); the forward equals the exact-f32 mode of the same library to 5e-4 and the
+    images do not depend on their position in the batch."""
+    cfg = synth.yml_unet_config(224)
+    e = _engine(cfg, synth.synth_state_dict(cfg, 3), "f16f8")
+    rs = np.random.RandomState(B)
+    x = rs.standard_normal((B, 6, 128, 128)).astype(np.float32)
+    x[B - 1] = x[0]
+    nl = np.full(B, 0.37, np.float32)
+    assert e.conv_f8_supported(B, 32, 32, 256, 256) and not e.conv_f8_supported(B, 16, 16, 512, 512)
+    got = e.unet_forward_np(x, nl)
+    e.set_precision("f32")
+    want = e.unet_forward_np(x, nl)
+    e.close()
+    err = np.abs(got - want).max()
+    print(f"B = {B}: f16f8 vs f32 {err:.2e}")
+    assert err < 5e-4
+    np.testing.assert_array_equal(got[0], got[B - 1])
+
+
 def test_sampler_golden_128px_full_schedule_replicated_f16f8():
     """BASELINE config 5's SR stage over its whole schedule (32 -> 128, T = 100; tests/golden/sampler_cfg5_32_128.npz,
     a run of the reference itself with B = 2), replicated to B = 64 with the same injected noise per replica pair."""
@@ -150,6 +172,8 @@ def test_sampler_golden_128px_full_schedule_replicated_f16f8():
     noise = np.tile(synth.synth_noise(T, B0, 3, r, r, m["seed"]), (1, rep, 1, 1, 1))
     cond = np.tile(g["cond"], (rep, 1, 1, 1))
     final, frames = e.sample_np(cond, noise=noise, frames=True)
+    again = e.sample_np(cond, noise=noise)
+    np.testing.assert_array_equal(again, final)          # no atomics on data anywhere: repeats are bit-identical
     assert e.fallback_calls() == 0
     e.close()
     want_f = np.tile(g["frames_sub"], (1, rep, 1, 1, 1))
