@@ -31,7 +31,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=str, default="", help="comma list of shape indices")
-    ap.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3"])
+    ap.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3", "f16f8"])
     args = ap.parse_args()
     if os.environ.get("SR3_LIB"):       # timing experiments with an alternative build of the library
         importlib.import_module(PKG + "._lib").LIB_PATH = os.path.abspath(os.environ["SR3_LIB"])

@@ -128,6 +128,90 @@ __global__ __launch_bounds__(256, 2) void loop_kernel(const uint4 *__restrict__ 
     out[blockIdx.x * 256 + tid] = s;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 32x32 consumers, 2 x 2 wave grid (wave tile 64 x 64: MI = NI = 2), as in the F8C path of conv3x3_halo_h3:
+//   W = 0  f16x3: per 32x32 tile and K-step 6 x v_mfma_f32_32x32x16_f16 (192 cycles)
+//   W = 1  f16+f8: 2 x v_mfma_f32_32x32x16_f16 + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 (128 cycles); the fp8 operand of a lane is
+//          its two lo chunks (4 + lh, 6 + lh) — the layout the instruction wants (finding 64)
+template <int W>
+__global__ __launch_bounds__(256, 2) void loop32_kernel(const uint4 *__restrict__ src, float *__restrict__ out, int steps) {
+    extern __shared__ __attribute__((aligned(128))) char lds[];      // [A stage 0][A stage 1][B 0][B 1]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 4 * STG / 16; i += 256) reinterpret_cast<uint4 *>(lds)[i] = src[(blockIdx.x & 7) * (5 * STG / 16) + i];
+    __syncthreads();
+    const int li = lane & 31, lh = lane >> 5, wm = w >> 1, wn = w & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int sw = (li >> 1) & 7;
+    const char *Abase = lds + (wm * 64 + li) * ROWB;
+    const char *Bbase = lds + 2 * STG + (wn * 64 + li) * ROWB;
+    for (int k = 0; k < steps; ++k) {
+        const int st = (k & 1) * STG;
+        h16x8 ah[2][2], bh[2][2];
+        i32x4 al[2][2], bl[2][2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char *ra = Abase + st + t * 32 * ROWB, *rb = Bbase + st + t * 32 * ROWB;
+                ah[sb][t] = *reinterpret_cast<const h16x8 *>(ra + (((2 * sb + lh) ^ sw) & 7) * 16);
+                al[sb][t] = *reinterpret_cast<const i32x4 *>(ra + (((4 + 2 * sb + lh) ^ sw) & 7) * 16);
+                bh[sb][t] = *reinterpret_cast<const h16x8 *>(rb + (((2 * sb + lh) ^ sw) & 7) * 16);
+                bl[sb][t] = *reinterpret_cast<const i32x4 *>(rb + (((4 + 2 * sb + lh) ^ sw) & 7) * 16);
+            }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sb][mi], bh[sb][ni], acc[mi][ni], 0, 0, 0);
+                    if (W == 0) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, al[sb][mi]), bh[sb][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sb][mi], __builtin_bit_cast(h16x8, bl[sb][ni]), acc[mi][ni], 0, 0, 0);
+                    }
+                }
+                if (W == 1)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                        __builtin_shufflevector(al[0][mi], al[1][mi], 0, 1, 2, 3, 4, 5, 6, 7),
+                        __builtin_shufflevector(bl[0][ni], bl[1][ni], 0, 1, 2, 3, 4, 5, 6, 7), acc[mi][ni], 0, 0, 0, 112, 0, 127);
+            }
+        asm volatile("" ::: "memory");
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int W>
+static double run32(const uint4 *src, float *out, int blocks, int steps, int reps) {
+    const size_t smem = 4 * STG;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(loop32_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    loop32_kernel<W><<<blocks, 256, smem>>>(src, out, steps);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int r = 0; r < reps; ++r) loop32_kernel<W><<<blocks, 256, smem>>>(src, out, steps);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
 template <int V>
 static double run(const uint4 *src, float *out, int blocks, int steps, int reps) {
     const size_t smem = 5 * STG;
@@ -169,16 +253,19 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&src, h.size() * 4));
     CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     CHECK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    const char *names[4] = {"f16x3 (3 f16 MFMA)", "f16+f8 (1 f16 + 1/2 fp8 K=128)", "f16x2 (2 f16 MFMA)", "f16x1 + the f8 reads"};
-    double ms[4];
+    const char *names[6] = {"16x16 f16x3 (3 f16 MFMA)", "16x16 f16+f8 (1 f16 + 1/2 fp8 K=128)", "16x16 f16x2 (2 f16 MFMA)", "16x16 f16x1 + the f8 reads",
+                            "32x32 f16x3 (6 f16 MFMA)", "32x32 f16+f8 (2 f16 + 1 fp8 K=64)"};
+    double ms[6];
     for (int rep = 0; rep < 2; ++rep) {
         ms[0] = run<0>(src, out, blocks, steps, reps);
         ms[1] = run<1>(src, out, blocks, steps, reps);
         ms[2] = run<2>(src, out, blocks, steps, reps);
         ms[3] = run<3>(src, out, blocks, steps, reps);
-        for (int v = 0; v < 4; ++v) {
+        ms[4] = run32<0>(src, out, blocks, steps, reps);
+        ms[5] = run32<1>(src, out, blocks, steps, reps);
+        for (int v = 0; v < 6; ++v) {
             const double flop = 2.0 * 128 * 128 * 32 * (double)steps * blocks;      // algorithmic: one product per MAC
-            printf("pass %d  %-32s %8.3f ms  %7.1f ns per K-step  %7.1f TFLOP/s algorithmic  (%.2fx of f16x3)\n", rep, names[v], ms[v],
+            printf("pass %d  %-40s %8.3f ms  %7.1f ns per K-step  %7.1f TFLOP/s algorithmic  (%.2fx of f16x3)\n", rep, names[v], ms[v],
                    ms[v] * 1e6 / steps, flop / (ms[v] * 1e-3) * 1e-12, ms[0] / ms[v]);
         }
     }
