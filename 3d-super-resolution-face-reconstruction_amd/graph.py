@@ -182,3 +182,37 @@ def upsample_flops_per_image(cfg: UNetConfig, h: int, w: int) -> float:
         h, w = 2 * h, 2 * w
         fl += 2.0 * h * w * ch * ch * 9
     return fl
+
+
+def resblock_conv3x3_shapes(cfg: UNetConfig, h: int, w: int):
+    """(h, w, cin, cout) of the two 3x3 convs of every ResnetBlock of one forward at h x w (unet.py:94-110, 161-233) —
+    the convs the f16f8 arithmetic may run with fp8 correction products (Engine.conv_f8_supported decides per shape)."""
+    inner, n = cfg.inner_channel, len(cfg.channel_mults)
+    out = []
+
+    def res(cin, cout, hh, ww):
+        out.append((hh, ww, cin, cout))
+        out.append((hh, ww, cout, cout))
+
+    pre = inner
+    feat = [pre]
+    for ind, mult in enumerate(cfg.channel_mults):
+        ch = inner * mult
+        for _ in range(cfg.res_blocks):
+            res(pre, ch, h, w)
+            feat.append(ch)
+            pre = ch
+        if ind != n - 1:
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            feat.append(pre)
+    res(pre, pre, h, w)
+    res(pre, pre, h, w)
+    for ind in reversed(range(n)):
+        ch = inner * cfg.channel_mults[ind]
+        for _ in range(cfg.res_blocks + 1):
+            res(pre + feat.pop(), ch, h, w)
+            pre = ch
+        if ind >= 1:
+            h, w = 2 * h, 2 * w
+    return out
+

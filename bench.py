@@ -266,19 +266,29 @@ def main():
         # MFMA work actually issued by the family: the sub-pixel Upsample convs execute 16/36 of their
         # algorithmic MACs, split-f16 issues 3 MFMA MACs per executed product
         up_alg = graph.upsample_flops_per_image(cfg, r, r) * B * K
-        executed = (conv["flops"] - up_alg * (20.0 / 36.0)) * (1.0 if args.precision == "f32" else 3.0)   # (f16f8: in f16-MFMA equivalents of f16x3)
+        executed = (conv["flops"] - up_alg * (20.0 / 36.0)) * (1.0 if args.precision == "f32" else 3.0)
+        f8c_alg = 0.0
+        if args.precision == "f16f8":
+            # convs on the fp8 correction path issue 2/3 of f16x3's MFMA cycles (two f16 MFMAs + one fp8 MFMA of twice the
+            # cycles instead of six): counted in f16-MFMA cycle equivalents
+            f8c_alg = sum(2.0 * hh * ww * co * ci * 9 for hh, ww, ci, co in graph.resblock_conv3x3_shapes(cfg, r, r)
+                          if eng.conv_f8_supported(B, hh, ww, co, ci)) * B * K
+            executed -= f8c_alg
+        roof_f8c_share = f8c_alg / conv["flops"] if conv["flops"] else 0.0
         roof = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak,
             "executed_frac": (executed / (conv["ms"] * 1e-3) / 1e12) / peak if conv["ms"] > 0 else 0.0,
             "executed_mfma_tflops": executed / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0,
+            "f8c_flop_share": roof_f8c_share,
             "traffic": (pmc_traffic(args.precision) / (n / K)) if pmc_traffic(args.precision) else None,
             "note": ("achieved = algorithmic conv FLOPs (the reference's conv arithmetic, SURVEY 8d) / HIP-event "
                      "time per logical conv; the Upsample convs execute 16/36 of their algorithmic MACs (sub-pixel "
                      "phases). " +
                      ("In f16x3 every executed MAC costs 3 MFMA MACs (matrix-pipe busy: see profiles/README.md)."
                       if args.precision == "f16x3" else
-                      ("f16x3 accounting; the fp8 correction products of the 32x32 / 16x16-pixel convs take half the cycles."
+                      ("executed_* in f16-MFMA cycle equivalents: 3 per product, 2 per product in the convs on the fp8 correction "
+                       "path (f8c_flop_share of the family's algorithmic FLOPs)."
                        if args.precision == "f16f8" else "Exact-f32 MFMA."))),
             "kernel": "conv family: conv3x3_halo_h3<...> + conv_igemm_dma_f32<...> (all tile shapes)",
             "launches_per_step": n / K,
