@@ -26,6 +26,11 @@ class Sr3RangeWarning(RuntimeWarning):
     """A call in split-f16 mode left the fp16 range and was finished in exact f32 (SR3_OK_F32_FALLBACK)."""
 
 
+class Sr3ReplayWarning(RuntimeWarning):
+    """Part of a call was replayed on the conv path without inter-block waits because another kernel held the compute
+    units an in-place split-K conv waits on (SR3_OK_REPLAYED); the result is complete and valid."""
+
+
 class UnetCfg(C.Structure):
     _fields_ = [
         ("in_channel", C.c_int32),
@@ -66,12 +71,15 @@ PROTOTYPES = {
     "sr3_set_schedule": (_I, [_P, _I, _F, _F, _F, _F, _F, _F]),
     "sr3_sample": (_I, [_P, _F, _I, _I, _I, _F, _U64, _U64, _F, _F]),
     "sr3_num_frames": (_I, [_P]),
+    "sr3_max_batch": (_I, [_P, _I, _I]),
     "sr3_sample_begin": (_I, [_P, _F, _I, _I, _I, _F, _U64, _U64]),
     "sr3_sample_step": (_I, [_P, _I, _F]),
     "sr3_sample_end": (_I, [_P, _F]),
     "sr3_range_check": (_I, [_P]),
     "sr3_set_range_policy": (_I, [_P, _I]),
     "sr3_fallback_calls": (_I, [_P]),
+    "sr3_replay_calls": (_I, [_P]),
+    "sr3_test_flag_address": (_P, [_P]),
     "sr3_last_warning": (C.c_char_p, []),
     "sr3_philox_normal": (_I, [_P, _U64, _U64, C.c_uint32, _I, _F]),
     "sr3_profile_enable": (_I, [_P, _I]),
@@ -120,16 +128,18 @@ def load() -> C.CDLL:
 
 
 SR3_OK_F32_FALLBACK = 1
+SR3_OK_REPLAYED = 2
 
 
 def check(rc: int) -> None:
-    """< 0: raise with the library's message; > 0 (SR3_OK_F32_FALLBACK): the result is valid, warn."""
+    """< 0: raise with the library's message; > 0 (SR3_OK_F32_FALLBACK, SR3_OK_REPLAYED): the result is valid, warn."""
     if rc == 0:
         return
     if rc > 0:
         import warnings
         msg = load().sr3_last_warning()
-        warnings.warn(Sr3RangeWarning(msg.decode("utf-8", "replace") if msg else "f32 fallback"), stacklevel=3)
+        kind = Sr3ReplayWarning if rc == SR3_OK_REPLAYED else Sr3RangeWarning
+        warnings.warn(kind(msg.decode("utf-8", "replace") if msg else "recomputed"), stacklevel=3)
         return
     msg = load().sr3_last_error()
     raise Sr3Error(msg.decode("utf-8", "replace") if msg else f"libsr3hip error {rc}")

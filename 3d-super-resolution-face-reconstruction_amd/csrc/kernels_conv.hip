@@ -566,7 +566,7 @@ __device__ __forceinline__ void producer_stats_tail(const ConvParams &p, const f
 // add that returns 3G - 1 stores 0, ready for the next launch — nobody polls any more by then).
 // No wait can hang by construction: a block only waits for blocks of its own group, which launch_conv orders so that
 // they are dispatched together (see conv_gnf_supported); should the hardware ever dispatch differently, the poll gives
-// up after 2^28 shader cycles (> 0.1 s), raises SR3_FLAG_GNF_TIMEOUT in *ovf (the API call fails) and the grid drains.
+// up after SR3_WAIT_TICKS of the 100 MHz real-time counter (5 ms), raises SR3_FLAG_GNF_TIMEOUT in *ovf and the grid drains.
 typedef unsigned __attribute__((address_space(1))) *gnf_cnt_ptr;
 typedef const double __attribute__((address_space(1))) *gnf_cdbl_ptr;
 typedef double __attribute__((address_space(1))) *gnf_dbl_ptr;
@@ -602,10 +602,10 @@ __device__ __forceinline__ void gnf_producer_tail(const ConvParams &p, float *sm
             // last arrival: every block of the group counted itself after its slice had completed
             __hip_atomic_store(rdy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            const long long t0 = __builtin_amdgcn_s_memtime();
+            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(16);
-                if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {     // 2^28 shader cycles (> 0.1 s): never in a healthy run
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > SR3_WAIT_TICKS) {     // 5 ms: never in a healthy run
                     if (p.ovf != nullptr) atomicOr(p.ovf, SR3_FLAG_GNF_TIMEOUT);
                     break;
                 }
@@ -1592,10 +1592,15 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
             if (threadIdx.x == 0) {
                 const unsigned arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (arrived + 1u < (unsigned)nsplit) {
-                    const long long t0 = __builtin_amdgcn_s_memtime();
+                    // Bounded wait (SR3_WAIT_TICKS of the constant 100 MHz counter = 5 ms). Liveness assumption: the
+                    // nsplit blocks of a tile are neighbours in the grid and the chip has a free slot for each of them —
+                    // true on an otherwise idle GPU (512 blocks for 512 slots at the 8x8 level of B = 64). If a co-tenant
+                    // kernel holds the slots a sibling needs, the wait gives up, the flag makes the API replay the work
+                    // with ConvParams::no_halo_split (a correct result either way, never a hang).
+                    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
                     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsplit) {
                         __builtin_amdgcn_s_sleep(8);
-                        if (__builtin_amdgcn_s_memtime() - t0 > (1ll << 28)) {        // 2^28 shader cycles (> 0.1 s): never in a healthy run
+                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > SR3_WAIT_TICKS) {
                             if (p.ovf != nullptr) atomicOr(p.ovf, SR3_FLAG_GNF_TIMEOUT);
                             break;
                         }
@@ -2198,7 +2203,7 @@ void launch_halo_pt(const ConvParams &p, hipStream_t s) {
     const int per_cu = std::min(128 / granules, BN == 64 ? 3 : 2);
     int grid = cus * per_cu;
     if (grid > ntiles) grid = ntiles;
-    static const int stagger = getenv("SR3_PT_STAGGER") ? atoi(getenv("SR3_PT_STAGGER")) : 0;
+    static const int stagger = exp_int("SR3_PT_STAGGER", 0);
     hipLaunchKernelGGL(kern, dim3(grid, 1, p.phases), dim3(512), lds, s, p, ntiles, stagger);
 }
 
@@ -2228,22 +2233,27 @@ void launch_halo(const ConvParams &p, hipStream_t s) {
 // (wave tile 32 x BN: all A fragments of a K-step are 4 registers x 4, the B columns stream through
 // two buffers); SR3_MFMA16=0 selects the 32x32x16 consumers (2 x 2 wave grid) for A/B measurements
 static bool halo_mfma16() {
-    static const int v = getenv("SR3_MFMA16") ? atoi(getenv("SR3_MFMA16")) : 1;
+    static const int v = exp_int("SR3_MFMA16", 1);
     return v != 0;
 }
 
 #ifdef SR3_EXPERIMENTS
 // persistent-tile form of the halo kernel (conv3x3_halo_pt, experiment): SR3_PERSIST=1
 static bool halo_persistent() {
-    static const int v = getenv("SR3_PERSIST") ? atoi(getenv("SR3_PERSIST")) : 0;
+    static const int v = exp_int("SR3_PERSIST", 0);
     return v != 0;
 }
 #endif
 
+// SR3_NO_HALO=1 (product safety switch): no x-halo kernel anywhere — and therefore no F8C path and no halo split-K
+static bool halo_off() {
+    static const int off = env_int("SR3_NO_HALO", 0);
+    return off != 0;
+}
+
 // preconditions of the x-halo kernel for tile height BM
 static bool halo_ok(const ConvParams &p, int BM, int segmin, int bn, bool split_ok = false) {
-    static const int off = getenv("SR3_NO_HALO") ? atoi(getenv("SR3_NO_HALO")) : 0;
-    if (off || p.prec != 1 || (p.ks != 3 && p.ks != 2) || p.stride != 1 || p.up2 || (p.splits > 1 && !split_ok) || p.in0.pad != 1) return false;
+    if (halo_off() || p.prec != 1 || (p.ks != 3 && p.ks != 2) || p.stride != 1 || p.up2 || (p.splits > 1 && !split_ok) || p.in0.pad != 1) return false;
     const int W = p.Wout;
     if (p.in0.W != W || p.in0.H != p.Hout) return false;
     const int seg = W < BM ? W : BM;
@@ -2384,8 +2394,8 @@ int splitk_stats_slices(int HWo, int Cout) {
 
 // tile choice: 0 = 128x32, 1 = 128x64, 2 = 64x64, 3 = 128x128
 static int conv_tile_choice(long M, int Cout) {
-    static const char *force = getenv("SR3_CONV_TILE");   // experiments only
-    if (force) return atoi(force);
+    static const int force = exp_int("SR3_CONV_TILE", -1);   // experiments build only
+    if (force >= 0) return force;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
     const long want = 512;  // 256 CUs x 2 resident blocks
     if (Cout <= 32) return 0;
@@ -2397,22 +2407,15 @@ static int conv_tile_choice(long M, int Cout) {
 int conv_tile_m(long M, int Cout) { return conv_tile_choice(M, Cout) == 2 ? 64 : 128; }
 
 int conv_splits(long M, int Cout, int Cin) {
-    static const int off = getenv("SR3_NO_SPLITK") ? atoi(getenv("SR3_NO_SPLITK")) : 0;
+    static const int off = exp_int("SR3_NO_SPLITK", 0);
     if (off || (Cout & 3)) return 1;
-#ifdef SR3_EXPERIMENTS
-    if (const char *f = getenv("SR3_FORCE_SPLITS")) return atoi(f);
-#endif
+    if (const int f = exp_int("SR3_FORCE_SPLITS", 0)) return f;
     static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
     const int t = conv_tile_choice(M, Cout);
     const long tiles = ((M + bm[t] - 1) / bm[t]) * ((Cout + bn[t] - 1) / bn[t]);
     const int nchunk = Cin / BK;
     // (tuned on B = 1 at 128x128 and config 1, with the in-place fix-up: profiles/README.md finding 42)
-    int tmin = 256, target = 256, chmin = 2;
-#ifdef SR3_EXPERIMENTS
-    if (const char *e = getenv("SR3_SPLIT_TMIN")) tmin = atoi(e);
-    if (const char *e = getenv("SR3_SPLIT_TARGET")) target = atoi(e);
-    if (const char *e = getenv("SR3_SPLIT_CHMIN")) chmin = atoi(e);
-#endif
+    const int tmin = exp_int("SR3_SPLIT_TMIN", 256), target = exp_int("SR3_SPLIT_TARGET", 256), chmin = exp_int("SR3_SPLIT_CHMIN", 2);
     if (tiles >= tmin || nchunk < 2 * chmin) return 1;
     int s = 2;
     while (s * 2 <= nchunk / chmin && tiles * s * 2 <= target && s < 16) s *= 2;
@@ -2426,8 +2429,8 @@ int conv_splits(long M, int Cout, int Cin) {
 // slice per 128-row tile, or one per image where a tile covers several whole images). 0 or 1: not for this shape.
 // Assumes ks 3, stride 1, prec 1, pad 1 (launch_conv checks them); sr3_api.hip sizes the partial buffer with it.
 int conv_halo_splits(long M, int H, int W, int Cout, int Cin) {
-    static const int force = getenv("SR3_HALO_SPLITS") ? atoi(getenv("SR3_HALO_SPLITS")) : -1;    // A/B: 0 off, N forced
-    if (force == 0 || !halo_mfma16()) return 0;
+    static const int force = env_int("SR3_HALO_SPLITS", -1);    // product switch: 0 off, 2 | 4 forced
+    if (force == 0 || halo_off() || !halo_mfma16()) return 0;
     const int HWo = H * W;
     if (W < 8 || (M % 128) || (Cout % 128) || (Cin % 32)) return 0;
     const int seg = W < 128 ? W : 128;
@@ -2448,8 +2451,9 @@ int conv_halo_splits(long M, int H, int W, int Cout, int Cin) {
 // 14-20 % faster than the f16x3 kernel (profiles/README.md finding 64); the 64x64- and 128x128-pixel levels are bound by
 // operand movement and gain nothing. Mirrors launch_conv's choice: callers format the conv's input accordingly.
 bool conv_f8_supported(int B, int H, int W, int Cout, int Cin) {
-    static const int off = getenv("SR3_NO_F8C") ? atoi(getenv("SR3_NO_F8C")) : 0;
-    static const int maxhw = getenv("SR3_F8C_MAX_HW") ? atoi(getenv("SR3_F8C_MAX_HW")) : 1024;
+    static const int off = exp_int("SR3_NO_F8C", 0);
+    static const int maxhw = exp_int("SR3_F8C_MAX_HW", 1024);
+    if (halo_off()) return false;            // (the F8C consumers exist in the x-halo kernel only)
     const long M = (long)B * H * W;
     const int HWo = H * W;
     if (off || (Cin % 32) || (Cout % 128) || (M % 128) || HWo > maxhw || HWo < 128 || (HWo % 128)) return false;
@@ -2460,7 +2464,7 @@ bool conv_f8_supported(int B, int H, int W, int Cout, int Cin) {
 }
 
 bool conv_split_inplace(long M, int HWo, int Cout, int Cin, int phases) {
-    static const int off = getenv("SR3_NO_INPLACE_SPLIT") ? atoi(getenv("SR3_NO_INPLACE_SPLIT")) : 0;
+    static const int off = env_int("SR3_NO_INPLACE_SPLIT", 0);
     if (off || conv_splits(M, Cout, Cin) <= 1) return false;
     static const int bm[4] = {128, 128, 64, 128}, bn[4] = {32, 64, 64, 128};
     const int t = conv_tile_choice(M, Cout);
@@ -2481,7 +2485,7 @@ static int gnf_kernel_choice(const ConvParams &p, int groups) {
     (void)p; (void)groups;
     return 0;
 #else
-    static const int on = getenv("SR3_GNF") ? atoi(getenv("SR3_GNF")) : 0;
+    static const int on = exp_int("SR3_GNF", 0);
     if (!on || !halo_mfma16() || p.prec != 1 || p.ks != 3 || p.stride != 1 || p.up2 || p.phases > 1 || groups <= 0) return 0;
     if (p.resid.p != nullptr || p.in2.p != nullptr || p.stats == nullptr) return 0;
     const int Cout = p.out.C, HWo = p.Hout * p.Wout;
@@ -2501,7 +2505,7 @@ static int gnf_kernel_choice(const ConvParams &p, int groups) {
     }
     if (!which || (bn % cg) != 0 || p.stats_slices != HWo / 128) return 0;
     if ((long)p.B * (Cout / bn) > CONV_GNF_COUNTERS) return 0;
-    static const int max_hw = getenv("SR3_GNF_MAX_HW") ? atoi(getenv("SR3_GNF_MAX_HW")) : (1 << 30);   // A/B: only images of at most this many pixels
+    static const int max_hw = exp_int("SR3_GNF_MAX_HW", 1 << 30);   // A/B: only images of at most this many pixels
     if (HWo > max_hw) return 0;
     // every (image, N-tile) group of TMI blocks must be able to be resident together: the standard block order keeps an
     // image's TMI x tilesN blocks on one XCD (32 CUs x 2 blocks at least); larger images use the band order, which
@@ -2518,12 +2522,15 @@ static int gnf_band_for(const ConvParams &p, int which) {
 }
 bool conv_gnf_supported(const ConvParams &p, int groups) { return gnf_kernel_choice(p, groups) != 0; }
 
+// first launch request of this thread that could not be honoured (nothing was launched for it); the API entry points
+// turn it into an error return (conv_take_error)
+static thread_local const char *g_conv_error = nullptr;
+const char *conv_take_error() { const char *e = g_conv_error; g_conv_error = nullptr; return e; }
+
 void launch_conv(const ConvParams &p_in, hipStream_t s) {
     if (p_in.up2) { launch_conv_up2(p_in, s); return; }     // weights must be in phase form (make_up2_phase_weights)
     ConvParams p = p_in;
-#ifdef SR3_EXPERIMENTS
-    if (const char *e = getenv("SR3_CONV_DBG")) p.dbg = atoi(e);
-#endif
+    p.dbg = exp_int("SR3_CONV_DBG", 0);
     const long M = (long)p.B * p.Hout * p.Wout;
     {
         auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
@@ -2532,7 +2539,7 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     }
     if (p.part == nullptr) p.splits = 1;
     if (p.prec == 1 && p.ks == 3 && p.stride == 1 && !p.up2 && p.phases == 1 && p.part != nullptr && p.tile_cnt != nullptr &&
-        p.in0.pad == 1 && p.in0.W == p.Wout && p.in0.H == p.Hout && p.gnf_gamma == nullptr) {
+        p.in0.pad == 1 && p.in0.W == p.Wout && p.in0.H == p.Hout && p.gnf_gamma == nullptr && !p.no_halo_split) {
         const int hs = conv_halo_splits(M, p.Hout, p.Wout, p.out.C, p.in0.C + (p.in1.p ? p.in1.C : 0));
         const int HWo = p.Hout * p.Wout;
         const bool stats_ok = p.stats == nullptr || p.stats_slices == (HWo >= 128 ? HWo / 128 : 1);
@@ -2558,7 +2565,7 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     if (p.gnf_gamma != nullptr) {
         // producer-side GroupNorm: the caller asked conv_gnf_supported() first
         const int which = gnf_kernel_choice(p, p.gnf_groups);
-        if (which == 0) { fprintf(stderr, "sr3: internal: producer-side GroupNorm requested for an unsupported conv\n"); abort(); }
+        if (which == 0) { g_conv_error = "internal: producer-side GroupNorm requested for an unsupported conv"; return; }
         p.gnf_band = gnf_band_for(p, which);
         if (which == 1) launch_halo<128, 64, 4, 1, 32, 3, 16, true>(p, s);
         else if (which == 2) launch_halo<128, 128, 4, 1, 32, 3, 16, true>(p, s);
@@ -2568,9 +2575,11 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
 #endif
     if (p.f8) {
         // the caller asked conv_f8_supported() first and wrote the input / passes the weights in the F8C format
+        // (conv_f8_supported is the single source of truth; a mismatch is a library bug, reported through the API's
+        // error path — nothing is launched, the process is never aborted)
         if (!(p.prec == 1 && p.ks == 3 && p.phases == 1 && p.splits <= 1 && halo_ok(p, 128, 8, 128))) {
-            fprintf(stderr, "sr3: internal: fp8 correction products requested for an unsupported conv\n");
-            abort();
+            g_conv_error = "internal: fp8 correction products requested for a conv the F8C kernel does not support";
+            return;
         }
         launch_halo<128, 128, 2, 2, 8, 3, 32, false, false, true>(p, s);
         return;

@@ -572,10 +572,7 @@ void launch_gn_apply_rows(const TDesc &in0, const TDesc &in1, int B, const float
 // pixels per block: enough blocks to keep every CU streaming (>= ~4 blocks of 512 threads per CU over
 // the whole grid), at least two items per thread
 static int ga_pixels_per_block(int B, int HW, int C8) {
-    int total = 1024;
-#ifdef SR3_EXPERIMENTS
-    if (const char *e = getenv("SR3_GN_BLOCKS")) total = atoi(e);
-#endif
+    const int total = exp_int("SR3_GN_BLOCKS", 1024);       // (experiments build reads the variable)
     int P = (total + B - 1) / B;                        // blocks per image wanted
     const int maxP = (HW * C8 + 2 * GA_T - 1) / (2 * GA_T);
     if (P > maxP) P = maxP;
@@ -1137,15 +1134,12 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
     hipLaunchKernelGGL(attention_vt_kernel, dim3(Np / 32, (C + 127) / 128, B), dim3(256), 0, s, qkv_split, N, C, vt);
     // 64 queries x 8 waves per block where that still leaves a block for every CU (config 3: B = 64, 256 tokens);
     // else 32 queries x 4 waves
-    static const int q64 = getenv("SR3_ATTN_Q64") ? atoi(getenv("SR3_ATTN_Q64")) : 1;
+    static const int q64 = exp_int("SR3_ATTN_Q64", 1);
     const bool big = q64 && (Np % 64) == 0 && (long)B * (Np / 64) >= 256 && (Np / 16 + 7) / 8 <= 2 && (C / 16 + 7) / 8 <= 4;
     const int QB = big ? 64 : 32, NW = big ? 8 : 4;
     const size_t lds = std::max((size_t)QB * (Np + 8) * sizeof(float), big ? (size_t)QB * (C * 4 + 32) : (size_t)0);
     const int ntw = (Np / 16 + NW - 1) / NW, ntc = (C / 16 + NW - 1) / NW;
-    int dbg = 0;
-#ifdef SR3_EXPERIMENTS
-    if (const char *e = getenv("SR3_ATTN_DBG")) dbg = atoi(e);
-#endif
+    const int dbg = exp_int("SR3_ATTN_DBG", 0);
 #define SR3_AT(A, B_, MQ, W_, CH_, KS_)                                                                            \
     {                                                                                                              \
         static size_t attr = 0;                                                                                    \
@@ -1157,7 +1151,7 @@ double launch_attention_split(const float *qkv_split, float *vt, int B, int N, i
         hipLaunchKernelGGL((attention_split_kernel<A, B_, MQ, W_, CH_, KS_>), dim3((Np / QB) * B), dim3(W_ * 64), lds, s, \
                            qkv_split, vt, N, C, out, out_split, ovf, dbg);                                         \
     }
-    static const int attn_static = getenv("SR3_ATTN_STATIC") ? atoi(getenv("SR3_ATTN_STATIC")) : 1;    // A/B: rolled two-set rings
+    static const int attn_static = exp_int("SR3_ATTN_STATIC", 1);    // A/B (experiments build): rolled two-set rings
     if (big && attn_static && C == 512 && Np == 256 && dbg == 0) SR3_AT(2, 4, 4, 8, 16, 8)     // config 3: unrolled, deep rings
     else if (big) SR3_AT(2, 4, 4, 8, 0, 0)       // (at most 256 tokens: 2 key tiles per wave)
     else if (ntw <= 2 && ntc <= 2) SR3_AT(2, 2, 2, 4, 0, 0)

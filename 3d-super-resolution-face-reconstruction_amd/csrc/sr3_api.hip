@@ -145,6 +145,11 @@ struct sr3_ctx {
     float *ckpt = nullptr;              // sr3_sample: NCHW copy of the sampler state at the last clean checkpoint
     size_t ckpt_floats = 0;
     unsigned *tile_cnt = nullptr;       // ConvParams::tile_cnt: arrival counters of the in-place split-K convs (zero between launches)
+    // Set (for the rest of the context's life) when a bounded inter-block wait of the in-place split-K on x-halo tiles
+    // gave up — a co-tenant kernel held the CU slots its sibling blocks needed (range_read): every conv then runs on a
+    // path whose blocks never wait for each other. Captured step graphs are rebuilt.
+    bool halo_split_off = false;
+    int replay_calls = 0;               // calls (or segments) replayed for that reason since sr3_create
     unsigned *gnf_cnt = nullptr;        // ConvParams::gnf_cnt: group counters of the producer-side GroupNorm (zero between launches)
     float *gnf_ab = nullptr;            // ConvParams::gnf_ab: [B][c_max][2] (workspace)
 
@@ -444,13 +449,31 @@ struct ShapePool {
 void drop_graphs(sr3_ctx *c);
 int prepare_f8(sr3_ctx *c);
 
+// largest batch one call can take at H x W: every activation tensor must stay below 4 GiB (32-bit byte offsets of the
+// conv's LDS-DMA addressing) and the padded pixel count below 2^31
+int max_batch(const sr3_ctx *c, int H, int W) {
+    const int div = 1 << (c->cfg.n_mults - 1);
+    if (H <= 0 || W <= 0 || (H % div) || (W % div)) return 0;
+    uint64_t per = (uint64_t)(H + 2) * (W + 2) * c->in_pad;          // floats per image of the widest tensor
+    int h = H, w = W;
+    for (const Module &m : c->mods) {
+        if (m.kind == M_DOWN) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+        else if (m.kind == M_UP) { h *= 2; w *= 2; }
+        uint64_t ch = m.kind == M_RES ? (uint64_t)m.rb.cout : (uint64_t)m.conv.cout;
+        if (m.kind == M_RES) ch = std::max<uint64_t>(ch, std::max<uint64_t>(m.rb.attn ? 3ull * m.rb.cout : 0ull, (uint64_t)m.rb.cin));
+        per = std::max(per, (uint64_t)(h + 2) * (w + 2) * ch);
+    }
+    const uint64_t by_bytes = ((1ull << 32) - 1) / (per * sizeof(float));
+    const uint64_t by_pix = ((1ull << 31) - 1) / ((uint64_t)(H + 2) * (W + 2));
+    return (int)std::min<uint64_t>(std::min(by_bytes, by_pix), 1u << 20);
+}
+
 int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     if (c->arena && c->wB == B && c->wH == H && c->wW == W) return 0;
     const sr3_unet_cfg &g = c->cfg;
     const int div = 1 << (g.n_mults - 1);
     if (B <= 0 || H <= 0 || W <= 0 || (H % div) || (W % div))
         return fail("unsupported shape B=%d H=%d W=%d: H and W must be multiples of %d", B, H, W, div);
-    if ((uint64_t)B * (H + 2) * (W + 2) >= (1ull << 31)) return fail("B*H*W too large for 32-bit pixel indices");
     if (c->arena) {
         HIP_OK(hipStreamSynchronize(c->stream));
         HIP_OK(hipFree(c->arena));
@@ -464,7 +487,7 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
     std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm), tw_off(nm);
     std::vector<char> twin(nm, 0);
-    static const int no_twin = getenv("SR3_NO_TWIN") ? atoi(getenv("SR3_NO_TWIN")) : 0;   // A/B: old copy / raw passes
+    static const int no_twin = exp_int("SR3_NO_TWIN", 0);   // A/B (experiments build): old copy / raw passes
     for (size_t i = 0; i < nm && !no_twin; ++i) {
         const bool skip = (int)i < c->n_downs;                       // consumed raw by an up-path res_conv
         const Module *nx = i + 1 < nm ? &c->mods[i + 1] : nullptr;
@@ -543,21 +566,11 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     (void)cur_c;
     if (h != H || w != W) return fail("internal: UNet does not return to the input resolution");
     {   // the conv's LDS-DMA addressing uses 32-bit byte offsets inside one tensor
-        uint64_t mx = (uint64_t)B * (H + 2) * (W + 2) * c->in_pad;
-        int hh = H, ww = W;
-        for (size_t i = 0; i < nm; ++i) {
-            const Module &m = c->mods[i];
-            uint64_t ch = m.oc;
-            if (m.kind == M_RES) ch = std::max<uint64_t>(ch, m.rb.attn ? 3ull * m.rb.cout : (uint64_t)m.rb.cin);
-            if (m.kind == M_RES) ch = std::max<uint64_t>(ch, (uint64_t)m.rb.cin);
-            mx = std::max(mx, (uint64_t)B * (m.oh + 2) * (m.ow + 2) * ch);
-            hh = m.oh; ww = m.ow;
-        }
-        (void)hh; (void)ww;
-        if (mx * sizeof(float) >= (1ull << 32))
-            return fail("batch %d at %dx%d makes an activation tensor of %.1f GiB (limit 4 GiB: 32-bit DMA offsets); "
-                        "run at most %llu images per call", B, H, W, mx * 4.0 / (1ull << 30),
-                        (unsigned long long)((uint64_t)B * ((1ull << 32) - 1) / (mx * 4)));
+        const int bmax = max_batch(c, H, W);
+        if (B > bmax)
+            return fail("batch %d at %dx%d makes an activation tensor of 4 GiB or more (32-bit DMA offsets inside one tensor); "
+                        "run at most %d images per call (sr3_max_batch; the Python facade chunks larger batches by itself)",
+                        B, H, W, bmax);
     }
     const uint64_t o_fa = acts.get(cv, B, c->final_gn.C, H, W);
     const uint64_t HW = (uint64_t)H * W;
@@ -640,7 +653,7 @@ void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int 
     // streaming kernel behind a separate finalize launch is faster than the folded form (A/B on one box,
     // profiles/README.md); below it the launch saved and the shorter critical path win
     const double pass_bytes = 8.0 * B * a.H * a.W * (a.C + (b.p ? b.C : 0));
-    static const double fold_max = getenv("SR3_GN_FOLD_MAX_MB") ? atof(getenv("SR3_GN_FOLD_MAX_MB")) * 1e6 : 200e6;
+    static const double fold_max = exp_double("SR3_GN_FOLD_MAX_MB", 200.0) * 1e6;
     // few images with many statistics slices (a single 128x128 image on 64x64 tiles leaves 256): the folded form's
     // prologue walks them in 12-16 dependent round trips in EVERY block (12-23 us per apply at B = 1); the
     // per-(image, group) finalize launch takes one round trip
@@ -687,6 +700,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
     p.splits = p.f8 ? 1 : conv_splits((long)B * out.H * out.W, cv.cout, a.C + (b.p ? b.C : 0));
     p.part = c->part;
     p.tile_cnt = c->tile_cnt;
+    p.no_halo_split = c->halo_split_off ? 1 : 0;
     p.ovf = c->d_ovf;
     if (cv2) {
         p.in2 = in2; p.in2b = in2b;
@@ -739,16 +753,19 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     const int h = m.oh, w = m.ow;
     // block1: GN+Swish(x ‖ skip) -> conv3x3 + bias + FeatureWiseAffine bias; the same pass stores
     // the raw concatenation for the fused res_conv
-    static const bool no_ident = getenv("SR3_NO_IDENT") && atoi(getenv("SR3_NO_IDENT"));   // A/B: epilogue gather
+    static const bool no_ident = exp_int("SR3_NO_IDENT", 0) != 0;   // A/B (experiments build): epilogue gather
     const bool direct = rb.has_res && xr.p && (!skip.p || skr.p);
-    const bool f8a = f8_conv(c, rb.c1, B, h, w), f8b = f8_conv(c, rb.c2, B, h, w);
+    // (conv2's fused 1x1 K-steps read x / skip — or the raw concatenation — in 32-channel chunks of the plain split format)
+    const bool fused_ok = !rb.has_res || (direct ? ((xr.C % 32) == 0 && (!skip.p || (skr.C % 32) == 0)) : (rb.cin % 32) == 0);
+    const bool f8a = f8_conv(c, rb.c1, B, h, w), f8b = fused_ok && f8_conv(c, rb.c2, B, h, w);
     run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, m.act1, sx, ss,
                rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0), f8a);
     // block1's conv + FeatureWiseAffine bias, then block2's GroupNorm + Swish: inside the conv where the producer-side
     // form applies (h1 then never exists: the conv writes act2), else as the apply pass over the fp32 h1
     bool gn2_done = false;
+    const bool want_gnf = c->prec && !c->no_fused_stats;     // (only then may the conv write act2 itself: h1 is never range-checked as a twin otherwise)
     run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1,
-             c->prec ? m.act2 : kNone, kNone, true, false, nullptr, c->prec && !c->no_fused_stats ? &rb.gn2 : nullptr, &gn2_done, f8a);
+             want_gnf ? m.act2 : kNone, kNone, true, false, nullptr, want_gnf ? &rb.gn2 : nullptr, &gn2_done, f8a);
     if (!gn2_done) run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef(), TDesc(), 0, f8b);
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
     // K-steps | + x as residual when the block keeps its width]
@@ -765,7 +782,7 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
-        static const bool attn_f32 = getenv("SR3_ATTN_F32") && atoi(getenv("SR3_ATTN_F32"));   // A/B: f32-MFMA core in f16x3 mode
+        static const bool attn_f32 = exp_int("SR3_ATTN_F32", 0) != 0;   // A/B (experiments build): f32-MFMA core in f16x3 mode
         if (c->prec && !attn_f32 && attention_split_supported(h * w, rb.cout)) {
             // split-f16 mode: the qkv projection writes ONLY the split twin of its output, the attention core
             // multiplies hi/lo halfs (3 x v_mfma_f32_16x16x32_f16 per product) and hands its result to the out
@@ -797,11 +814,11 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
     // split-only mode: a module output that has a twin is written ONLY as the twin (4 instead of 8
     // bytes per element); GroupNorm apply and residual adds read hi + lo. Needs every GroupNorm to get
     // its statistics from a conv epilogue (the fallback statistics kernel reads fp32 tensors).
-    static const bool so_off = getenv("SR3_NO_SPLIT_ONLY") && atoi(getenv("SR3_NO_SPLIT_ONLY"));
+    static const bool so_off = exp_int("SR3_NO_SPLIT_ONLY", 0) != 0;
     const bool so_mode = c->prec && c->all_fused && !c->no_fused_stats && !so_off;
     const int n_pre = c->n_downs + c->n_mid;
-    static const bool no_direct = getenv("SR3_NO_TWIN") && atoi(getenv("SR3_NO_TWIN"));   // A/B: raw-concatenation pass
-    static const bool no_edge = getenv("SR3_NO_EDGE") && atoi(getenv("SR3_NO_EDGE"));     // A/B: generic kernels for downs.0 / final_conv
+    static const bool no_direct = exp_int("SR3_NO_TWIN", 0) != 0;   // A/B (experiments build): raw-concatenation pass
+    static const bool no_edge = exp_int("SR3_NO_EDGE", 0) != 0;     // A/B (experiments build): generic kernels for downs.0 / final_conv
     for (int i = 0; i < (int)c->mods.size(); ++i) {
         Module &m = c->mods[i];
         const bool is_up_path = i >= n_pre;
@@ -883,7 +900,7 @@ void run_unet_body(sr3_ctx *c, int B, int H, int W) {
                                     c->gpart, c->gscale, c->gshift, c->stream);
         c->pend();
         c->pbegin(F_CONV);
-        static const bool final_valu = getenv("SR3_FINAL_VALU") && atoi(getenv("SR3_FINAL_VALU"));   // A/B: fp32 VALU form in f16x3 mode
+        static const bool final_valu = exp_int("SR3_FINAL_VALU", 0) != 0;   // A/B (experiments build): fp32 VALU form in f16x3 mode
         const bool mfma = c->prec && c->final_wm && !final_valu;
         if (mfma)
             launch_final_conv_mfma(cur, B, c->gscale, c->gshift, c->final_wm, c->final_unscale, c->params[c->final_conv.b].dev,
@@ -995,17 +1012,39 @@ int range_reset(sr3_ctx *c) {
 // Synchronises the stream and fails if any kernel since the last reset stored a value beyond the
 // fp16 range in the split-f16 format (such a value would otherwise corrupt the residual stream
 // silently). The flag is cleared either way.
-// synchronises, reads and clears the flag: 0 in range, 1 overflow, -1 HIP error
+// synchronises, reads and clears the flag: 0 in range, 1 overflow, -1 HIP error, and
+// 2: a bounded inter-block wait of the in-place split-K on x-halo tiles gave up (SR3_FLAG_GNF_TIMEOUT) — some other kernel
+//    held the CU slots the tile's sibling blocks needed. Everything computed since the last reset is invalid (the flag may
+//    carry a bogus overflow bit from the incomplete sums as well). The context is switched to the conv path whose blocks
+//    never wait for each other (halo_split_off; captured graphs dropped) and the CALLER REPLAYS the work: the call still
+//    finishes with a correct result, it never hangs and never fails for this reason.
 int range_read(sr3_ctx *c) {
     HIP_OK(hipMemcpyAsync(c->h_ovf, c->d_ovf, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     if (*c->h_ovf == 0) return 0;
     const int v = *c->h_ovf;
     HIP_OK(hipMemsetAsync(c->d_ovf, 0, sizeof(int), c->stream));
-    if (v & SR3_FLAG_GNF_TIMEOUT)
-        return fail("internal: blocks of one conv tile that wait for each other (in-place split-K) were not dispatched "
-                    "together and the bounded wait gave up; the result is invalid — set SR3_HALO_SPLITS=0 and report this");
+    if (v & SR3_FLAG_GNF_TIMEOUT) {
+        c->halo_split_off = true;
+        drop_graphs(c);
+        // (every block still counts its arrival and departure, so the counters return to zero by themselves; the stream
+        // is idle here, so clearing them is free insurance)
+        HIP_OK(hipMemsetAsync(c->tile_cnt, 0, CONV_TILE_COUNTERS * sizeof(unsigned), c->stream));
+        return 2;
+    }
     return 1;
+}
+
+// the call was finished after replaying work whose in-place split-K wait had timed out (range_read == 2)
+int warn_replay(sr3_ctx *c, const char *what, const char *redo) {
+    char buf[640];
+    snprintf(buf, sizeof buf, "%s: another kernel held the compute units that the blocks of an in-place split-K conv tile "
+             "wait for each other on, and the bounded wait (5 ms) gave up; %s was recomputed on the conv path without "
+             "inter-block waits, which this context uses from now on (slightly slower at the 8x8 level). The result is "
+             "complete and valid. SR3_HALO_SPLITS=0 selects that path from the start.", what, redo);
+    g_warn = buf;
+    ++c->replay_calls;
+    return SR3_OK_REPLAYED;
 }
 
 // to_f16x3: only the fp8 operand range of the "f16f8" mode was exceeded and the plain split-f16 arithmetic held the rest
@@ -1025,11 +1064,25 @@ int warn_fallback(sr3_ctx *c, const char *what, const char *redo, bool to_f16x3 
     return SR3_OK_F32_FALLBACK;
 }
 
+int range_fail(sr3_ctx *c, const char *what) {
+    if (c->f8corr)
+        return fail("%s: an activation exceeded the operand range of the f16f8 arithmetic — the fp8 range (|v| > %g) in a "
+                    "conv on the fp8 correction path, or the fp16 range (|v| > 65504) of the split-f16 format elsewhere; "
+                    "the result is invalid — run this model in f16x3 (sr3_set_precision(ctx, 1): no fp8 operands) or, if "
+                    "that overflows too, with the exact f32 arithmetic (sr3_set_precision(ctx, 0))", what, (double)SPLIT_F8_MAX);
+    return fail("%s: an activation exceeded the fp16 range (|v| > 65504) of the split-f16 format; the result is "
+                "invalid — run this model with the exact f32 arithmetic (sr3_set_precision(ctx, 0))", what);
+}
+
+// step API / single ops: the caller owns the inputs, the library cannot replay — fail, naming the remedy
 int range_check(sr3_ctx *c, const char *what) {
     const int r = range_read(c);
     if (r <= 0) return r;
-    return fail("%s: an activation exceeded the fp16 range (|v| > 65504) of the split-f16 format; the result is "
-                "invalid — run this model with the exact f32 arithmetic (sr3_set_precision(ctx, 0))", what);
+    if (r == 2)
+        return fail("%s: another kernel held the compute units an in-place split-K conv waits on and its bounded wait gave "
+                    "up: this result is invalid; the context now uses the conv path without inter-block waits — repeat the "
+                    "call (sr3_sample / sr3_unet_forward replay by themselves)", what);
+    return range_fail(c, what);
 }
 
 int check_ready(sr3_ctx *c) {
@@ -1110,6 +1163,12 @@ int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
     return 0;
 }
 
+int step_checked(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
+    if (step_impl(c, t, noise_slab, frame)) return -1;
+    if (const char *e = conv_take_error()) return fail("p_sample step t=%d: %s", t, e);
+    return 0;
+}
+
 } // namespace
 
 // =================================================================================================
@@ -1138,8 +1197,8 @@ int sr3_create(const sr3_unet_cfg *cfg, int device, sr3_ctx **out) {
     sr3_ctx *c = new sr3_ctx();
     c->cfg = *cfg;
     c->device = device;
-    if (const char *e = getenv("SR3_NO_FUSED_STATS")) c->no_fused_stats = atoi(e) != 0;
-    if (const char *e = getenv("SR3_NO_GRAPH")) c->no_graph = atoi(e) != 0;
+    c->no_fused_stats = exp_int("SR3_NO_FUSED_STATS", 0) != 0;      // experiments build only
+    c->no_graph = env_int("SR3_NO_GRAPH", 0) != 0;                  // product switch
     if (build_graph(c)) { delete c; return -1; }
     if (alloc_weights(c)) { sr3_destroy(c); return -1; }
     if (hipStreamCreate(&c->own_stream) != hipSuccess) { sr3_destroy(c); return fail("hipStreamCreate failed"); }
@@ -1329,6 +1388,7 @@ static int unet_forward_once(sr3_ctx *c, const float *x_dev, const float *noise_
     launch_nhwc_to_nchw(c->eps, 0, B, c->cfg.out_channel, out_dev, c->stream);
     c->pend();
     HIP_OK(hipGetLastError());
+    if (const char *e = conv_take_error()) return fail("sr3_unet_forward: %s", e);
     return 0;
 }
 
@@ -1340,9 +1400,17 @@ int sr3_unet_forward(sr3_ctx *c, const float *x_dev, const float *noise_level_de
     c->sampling = false;
     if (unet_forward_once(c, x_dev, noise_level_dev, B, H, W, out_dev)) return -1;
     if (!c->prec) return 0;
-    if (c->strict_range) return range_check(c, "sr3_unet_forward");
-    const int r = range_read(c);
-    if (r <= 0) return r;
+    int r = range_read(c);
+    bool replayed = false;
+    if (r == 2) {       // an in-place split-K wait gave up: evaluate again on the non-waiting path (same arithmetic)
+        replayed = true;
+        if (unet_forward_once(c, x_dev, noise_level_dev, B, H, W, out_dev)) return -1;
+        r = range_read(c);
+        if (r == 2) return fail("internal: inter-block wait flag raised with the in-place split-K disabled");
+    }
+    if (r < 0) return -1;
+    if (r == 0) return replayed ? warn_replay(c, "sr3_unet_forward", "the forward pass") : 0;
+    if (c->strict_range) return range_fail(c, "sr3_unet_forward");
     // out of range: the caller still owns x and noise_level, so the forward is simply evaluated again — f16f8 first
     // without the fp8 products (their operand range is the narrower one), then in f32
     if (c->f8corr) {
@@ -1380,6 +1448,13 @@ int sr3_set_schedule(sr3_ctx *c, int T, const float *noise_level, const float *r
     return 0;
 }
 
+int sr3_max_batch(sr3_ctx *c, int H, int W) {
+    if (!c) return fail("null context");
+    const int b = max_batch(c, H, W);
+    if (b <= 0) return fail("unsupported shape H=%d W=%d: H and W must be multiples of %d", H, W, 1 << (c->cfg.n_mults - 1));
+    return b;
+}
+
 int sr3_num_frames(sr3_ctx *c) {
     if (!c) return fail("null context");
     if (c->T < 1) return fail("no schedule set");
@@ -1413,7 +1488,7 @@ int sr3_sample_begin(sr3_ctx *c, const float *cond_dev, int B, int H, int W, con
 int sr3_sample_step(sr3_ctx *c, int t, const float *noise_slab_dev) {
     if (!c) return fail("null context");
     HIP_OK(hipSetDevice(c->device));
-    if (step_impl(c, t, noise_slab_dev, nullptr)) return -1;
+    if (step_checked(c, t, noise_slab_dev, nullptr)) return -1;
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1443,12 +1518,17 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
     const int T = c->T, si = 1 | (T / 10);
     const int C = c->cfg.out_channel, nc = c->cfg.in_channel - C;
     const size_t slab = (size_t)B * C * H * W;
-    // Range guard of the split-f16 mode (default policy): the loop is cut into segments of `seg` steps. At every
-    // segment boundary the range flag is read (one stream synchronisation per segment: ~10 per call); while it is
-    // clean the sampler state is saved (NCHW copy, 12 B per pixel). When it trips, the state of the last clean
-    // boundary is restored and the REST of the loop runs in the exact-f32 arithmetic — every draw of the noise
-    // (injected slab or Philox draw index) and every frame slot is a function of t, so the replay is exact.
-    const bool guard = c->prec == 1 && !c->strict_range;
+    // Guard of the split-f16 modes: the loop is cut into segments of `seg` steps. At every segment boundary the device
+    // flag is read (one stream synchronisation per segment: ~10 per call); while it is clean the sampler state is saved
+    // (NCHW copy, 12 B per pixel). Two things can raise it:
+    //  * RANGE (an activation beyond the operand format). Default policy: the state of the last clean boundary is
+    //    restored and the REST of the loop runs one arithmetic down (f16f8 -> f16x3 -> exact f32) — every draw of the
+    //    noise (injected slab or Philox draw index) and every frame slot is a function of t, so the replay is exact.
+    //    Strict policy: the call fails at that boundary.
+    //  * an in-place split-K WAIT that gave up because a co-tenant kernel held the CU slots (range_read == 2): the
+    //    context has switched to the non-waiting conv path; the segment is replayed from the boundary in the SAME
+    //    arithmetic, whatever the policy.
+    const bool guard = c->prec == 1;
     const int seg = std::max(1, T / 10);
     if (guard && c->ckpt_floats < slab) {
         if (c->ckpt) HIP_OK(hipFree(c->ckpt));
@@ -1457,49 +1537,55 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
         c->ckpt_floats = slab;
     }
     auto save = [&]() { launch_nhwc_to_nchw(c->x0, nc, B, C, c->ckpt, c->stream); };
+    auto restore = [&]() {
+        launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
+        if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
+    };
     // back to the last clean boundary, one arithmetic down from here on: f16f8 -> f16x3 (the fp8 operands have the
     // narrower range; the guard stays on) -> exact f32 (the mode is restored before the call returns)
     const bool f8_was = c->f8corr;
     auto fall_back = [&]() {
-        launch_init_state(c->x0, nc, C, c->ckpt, seed, image_offset, B, c->stream);
-        if (c->x0p) launch_pack_state(c->x0, B, c->x0p, c->stream, c->d_ovf);
+        restore();
         if (c->f8corr) c->f8corr = false;
         else c->prec = 0;
     };
     int t_ck = T - 1, f_ck = 0;          // the checkpoint holds the state BEFORE step t_ck; f_ck frames were written by then
-    bool fell_back = false;              // exact f32 from here on: no more range checks
-    bool any_fallback = false;
+    bool fell_back = false;              // exact f32 from here on: no more checks
+    bool any_fallback = false, replayed = false;
     int rc = 0;
     if (guard) {
         const int r = range_read(c);     // (the initial state / its packed copy)
         if (r < 0) return -1;
-        if (r > 0) { c->prec = 0; fell_back = any_fallback = true; }
+        if (r == 1 && c->strict_range) return range_fail(c, "sr3_sample");
+        if (r == 1) { c->prec = 0; fell_back = any_fallback = true; }
         else save();
     }
     int f = 0;
+    // boundary check: 0 = clean (checkpoint taken by the caller), 1 = rewound to the checkpoint, -1 = error (rc set)
+    auto boundary = [&]() -> int {
+        const int r = range_read(c);
+        if (r < 0) { rc = -1; return -1; }
+        if (r == 0) return 0;
+        if (r == 2) { restore(); replayed = true; return 1; }
+        if (c->strict_range) { rc = range_fail(c, "sr3_sample"); return -1; }
+        fall_back(); fell_back = c->prec == 0; any_fallback = true;
+        return 1;
+    };
     for (int t = T - 1; t >= 0; --t) {
         if (guard && !fell_back && t != T - 1 && ((T - 1 - t) % seg) == 0) {
-            const int r = range_read(c);
-            if (r < 0) { rc = -1; break; }
-            if (r > 0) {
-                fall_back(); fell_back = c->prec == 0; any_fallback = true;
-                t = t_ck; f = f_ck;
-            } else {
-                save();
-                t_ck = t; f_ck = f;
-            }
+            const int b = boundary();
+            if (b < 0) break;
+            if (b == 1) { t = t_ck; f = f_ck; }
+            else { save(); t_ck = t; f_ck = f; }
         }
         const float *nz = (noise_dev && t > 0) ? noise_dev + (size_t)(T - t) * slab : nullptr;
         float *fr = (frames_dev && (t % si == 0)) ? frames_dev + (size_t)(f++) * slab : nullptr;
-        if (step_impl(c, t, nz, fr)) { rc = -1; break; }
+        if (step_checked(c, t, nz, fr)) { rc = -1; break; }
         if (c->prof && (t % 8) == 0) c->pflush();  // bound the number of live events
         if (guard && !fell_back && t == 0) {        // the last segment
-            const int r = range_read(c);
-            if (r < 0) { rc = -1; break; }
-            if (r > 0) {
-                fall_back(); fell_back = c->prec == 0; any_fallback = true;
-                t = t_ck + 1; f = f_ck;             // (the loop's --t resumes at t_ck)
-            }
+            const int b = boundary();
+            if (b < 0) break;
+            if (b == 1) { t = t_ck + 1; f = f_ck; }             // (the loop's --t resumes at t_ck)
         }
     }
     if (rc == 0) {
@@ -1514,9 +1600,10 @@ int sr3_sample(sr3_ctx *c, const float *cond_dev, int B, int H, int W, const flo
         }
     }
     const bool to_f16x3 = any_fallback && !fell_back;
-    if (any_fallback) { c->prec = 1; c->f8corr = f8_was; }
+    if (guard) { c->prec = 1; c->f8corr = f8_was; }
     if (rc) return rc;
-    return any_fallback ? warn_fallback(c, "sr3_sample", "the rest of the loop from the last in-range checkpoint", to_f16x3) : 0;
+    if (any_fallback) return warn_fallback(c, "sr3_sample", "the rest of the loop from the last in-range checkpoint", to_f16x3);
+    return replayed ? warn_replay(c, "sr3_sample", "the segment of T/10 steps it happened in") : 0;
 }
 
 int sr3_set_range_policy(sr3_ctx *c, int strict) {
@@ -1525,6 +1612,8 @@ int sr3_set_range_policy(sr3_ctx *c, int strict) {
     return 0;
 }
 int sr3_fallback_calls(sr3_ctx *c) { return c ? c->fallback_calls : fail("null context"); }
+int sr3_replay_calls(sr3_ctx *c) { return c ? c->replay_calls : fail("null context"); }
+void *sr3_test_flag_address(sr3_ctx *c) { return c ? c->d_ovf : nullptr; }
 const char *sr3_last_warning(void) { return g_warn.c_str(); }
 
 int sr3_philox_normal(sr3_ctx *c, uint64_t seed, uint64_t image, uint32_t draw, int n, float *out_dev) {
@@ -1649,15 +1738,29 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
             p.tile_cnt = c->tile_cnt;
         }
     }
-    if (up2) launch_conv_up2(p, c->stream);
-    else launch_conv(p, c->stream);
-    HIP_OK(hipStreamSynchronize(c->stream));
+    // (this entry point owns its inputs: an in-place split-K wait that gave up — range_read == 2 — is answered by running
+    // the conv again on the non-waiting path, as sr3_unet_forward / sr3_sample do)
+    int rc = 0;
+    bool replayed = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        p.no_halo_split = c->halo_split_off ? 1 : 0;
+        if (up2) launch_conv_up2(p, c->stream);
+        else launch_conv(p, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) { rc = fail("sr3_op_conv2d: launch failed"); break; }
+        if (const char *e = conv_take_error()) { rc = fail("sr3_op_conv2d: %s", e); break; }
+        if (!c->prec) break;
+        const int r = range_read(c);
+        if (r == 2 && attempt == 0) { replayed = true; continue; }
+        rc = r == 0 ? 0 : (r < 0 ? -1 : (r == 2 ? fail("internal: inter-block wait flag raised with the in-place split-K disabled")
+                                                 : range_fail(c, "sr3_op_conv2d")));
+        break;
+    }
     HIP_OK(hipFree(dw));
     HIP_OK(hipFree(act));
     if (db) HIP_OK(hipFree(db));
     if (part) HIP_OK(hipFree(part));
-    HIP_OK(hipGetLastError());
-    return c->prec ? range_check(c, "sr3_op_conv2d") : 0;
+    if (rc) return rc;
+    return replayed ? warn_replay(c, "sr3_op_conv2d", "the conv") : 0;
 }
 
 // Times `iters` launches of one conv shape on scratch buffers (random contents; f32 MFMA time does

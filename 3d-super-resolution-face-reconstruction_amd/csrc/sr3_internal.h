@@ -3,7 +3,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace sr3 {
+
+// ---- environment switches ---------------------------------------------------------------------------
+// PRODUCT switches (INTEGRATION.md lists them; each is read once per process and then baked into captured graphs):
+//   SR3_NO_GRAPH=1          every kernel launched individually, no hipGraph replay (hosts that cannot capture)
+//   SR3_NO_HALO=1           generic implicit-GEMM kernel instead of the x-halo kernels (safety switch; slower)
+//   SR3_HALO_SPLITS=0|2|4   in-place split-K of deep-K convs on 128x128 x-halo tiles: off / forced
+//   SR3_NO_INPLACE_SPLIT=1  split-K always as conv + reduce kernel
+// Everything else is an A/B switch of the development build (-DSR3_EXPERIMENTS, build.py --experiments): the product
+// library does not read those variables at all, so a stray one cannot change kernels or numerics.
+inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#ifdef SR3_EXPERIMENTS
+inline int exp_int(const char *name, int dflt) { return env_int(name, dflt); }
+inline double exp_double(const char *name, double dflt) { const char *e = getenv(name); return e ? atof(e) : dflt; }
+#else
+inline int exp_int(const char *, int dflt) { return dflt; }
+inline double exp_double(const char *, double dflt) { return dflt; }
+#endif
 
 // Activation tensor: NHWC fp32 with an optional 1-pixel zero border ("pad") stored around every
 // image, so a 3x3 window never needs a bounds check: pixel (n, y, x) lives at
@@ -87,6 +106,10 @@ struct ConvParams {
     // epilogue itself (no reduce kernel; fused statistics in the unsplit layout: one slice per M-tile).
     // nullptr: always the two-kernel form.
     unsigned *tile_cnt = nullptr;
+    // 1: never the in-place split-K of the 128x128 x-halo tile (conv_halo_splits) — set for the rest of a context's
+    // life once one of its bounded inter-block waits gave up (SR3_FLAG_GNF_TIMEOUT): the conv then runs unsplit on the
+    // generic 64x64 tile, whose blocks never wait for each other
+    int no_halo_split = 0;
     // split-f16 range check: any value stored in the split format (out_split) with |v| > 65504 (or
     // non-finite) sets *ovf = 1; the API call that ran the launch then fails (never a silent clamp)
     int *ovf = nullptr;
@@ -110,8 +133,12 @@ struct ConvParams {
     int dbg = 0;            // timing experiments only (tools/conv_bench.py); 0 in product code
 };
 // bit raised in *ConvParams::ovf when a bounded inter-block wait gives up (in-place split-K of the x-halo kernel; the
-// producer-side GroupNorm experiment): the API call then fails
+// producer-side GroupNorm experiment): the launch's result is invalid; the API replays the work with
+// ConvParams::no_halo_split set (sr3_api.hip: range_read)
 constexpr int SR3_FLAG_GNF_TIMEOUT = 2;
+// bound of such a wait in ticks of s_memrealtime (constant 100 MHz on gfx950, MI355X_MICROARCH.md): 2^19 = 5.2 ms — the
+// blocks of one tile are dispatched back to back and the whole conv takes < 0.1 ms on an idle chip
+constexpr long long SR3_WAIT_TICKS = 1ll << 19;
 // largest magnitude the split-f16 format (hi + lo, both fp16) can hold
 constexpr float SPLIT_F16_MAX = 65504.0f;
 
@@ -145,6 +172,9 @@ bool conv_f8_supported(int B, int H, int W, int Cout, int Cin);
 // split weights [chunks][32 hi | 32 lo] -> F8C weights [chunks][32 hi | 32 wh8 | 32 wl8] (device to device)
 void launch_make_f8_weights(const float *split, float *dst, size_t chunks, hipStream_t s);
 void launch_conv(const ConvParams &p, hipStream_t s);
+// launch_conv never aborts the process: a request it cannot honour (a caller / library bug) launches nothing and leaves
+// a message here; returns it once (nullptr if none) — the C-ABI entry points fail the call with it
+const char *conv_take_error();
 // Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
 // parity (py, px) see only a 2x2 window of the low-resolution input, with the 3x3 taps that land
 // on the same source pixel pre-added (make_up2_phase_weights) — 16 instead of 36 MACs per

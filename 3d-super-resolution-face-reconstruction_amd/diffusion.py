@@ -77,40 +77,86 @@ class GaussianDiffusion(nn.Module):
         # as with the reference's torch.randn calls (the streams themselves differ: Philox on device)
         return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
+    @staticmethod
+    def chunk_plan(B: int, limit: int):
+        """Equal chunks for a batch above the per-call limit: (n_chunks, chunk) with n_chunks * chunk >= B and the
+        fewest chunks; the last one is PADDED to `chunk` images (rows discarded) so that every chunk runs the same
+        workspace, the same captured graph and the same kernels (the tile rule depends on the batch)."""
+        if B <= limit:
+            return 1, B
+        n = -(-B // limit)
+        return n, -(-B // n)
+
     @torch.no_grad()
     def sample_batch(self, x_in, continous=False, noise: Optional[torch.Tensor] = None,
-                     seed: Optional[int] = None, image_offset: int = 0):
+                     seed: Optional[int] = None, image_offset: int = 0, max_chunk: Optional[int] = None):
         """p_sample_loop for a whole batch (diffusion.py:189-215).
 
         x_in: conditioning [B,3,H,W] (conditional) or a shape tuple (unconditional, :193-201).
         noise: optional [T,B,C,H,W] tensor replacing the RNG (slab 0 = initial image, slab k = the
         randn_like of step t=T-k). Returns [B,C,H,W], or (final, frames [n,B,C,H,W]) if continous.
+
+        Batches above the library's per-call limit (4 GiB per activation tensor: ~250 images at 128x128) — the
+        reference's validation loop is 15 samples x N images (lib/trainer_temp.py:441-446), BASELINE configs[3] is 512
+        images — run as equal chunks, one sr3_sample call each; Philox streams stay keyed by the GLOBAL image index
+        (image_offset + row), so the result does not depend on the chunking. max_chunk lowers the limit (tests).
         """
         eng = self._engine()
         if self.conditional:
             x = x_in.to(torch.float32).contiguous()
             B, _, H, W = x.shape
-            dev, cond_ptr = x.device, x.data_ptr()
+            dev = x.device
         else:
             B, _, H, W = tuple(x_in)
-            dev, cond_ptr = next(self.denoise_fn.parameters()).device, None
+            dev, x = next(self.denoise_fn.parameters()).device, None
         C = self.channels
+        T = self.num_timesteps
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=dev)
         frames = None
         if continous:
             frames = torch.empty((eng.num_frames(), B, C, H, W), dtype=torch.float32, device=dev)
-        nptr = None
         if noise is not None:
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
-            if tuple(noise.shape) != (self.num_timesteps, B, C, H, W):
-                raise RuntimeError(f"noise must be {(self.num_timesteps, B, C, H, W)}, got {tuple(noise.shape)}")
-            nptr = noise.data_ptr()
+            if tuple(noise.shape) != (T, B, C, H, W):
+                raise RuntimeError(f"noise must be {(T, B, C, H, W)}, got {tuple(noise.shape)}")
         if seed is None:
             seed = self._draw_seed()
-        self.denoise_fn.ready()
-        eng.sample(cond_ptr, B, H, W, out.data_ptr(), nptr, seed, image_offset,
-                   frames.data_ptr() if frames is not None else None)
-        self.denoise_fn.finish()
+        limit = eng.max_batch(H, W)
+        if max_chunk is not None:
+            limit = max(1, min(limit, int(max_chunk)))
+        n_chunks, chunk = self.chunk_plan(B, limit)
+        if n_chunks == 1:
+            self.denoise_fn.ready()
+            eng.sample(x.data_ptr() if x is not None else None, B, H, W, out.data_ptr(),
+                       noise.data_ptr() if noise is not None else None, seed, image_offset,
+                       frames.data_ptr() if frames is not None else None)
+            self.denoise_fn.finish()
+            return (out, frames) if continous else out
+
+        def rows(t, a, b, dim):
+            """rows [a, b) of `t` along `dim`, padded to `chunk` rows by repeating the last one, contiguous"""
+            part = t.narrow(dim, a, b - a)
+            if b - a < chunk:
+                last = part.narrow(dim, b - a - 1, 1)
+                part = torch.cat([part] + [last] * (chunk - (b - a)), dim=dim)
+            return part.contiguous()
+
+        for k in range(n_chunks):
+            a, b = k * chunk, min(B, (k + 1) * chunk)
+            xc = rows(x, a, b, 0) if x is not None else None
+            nc = rows(noise, a, b, 1) if noise is not None else None
+            whole = b - a == chunk
+            oc = out[a:b] if whole else torch.empty((chunk, C, H, W), dtype=torch.float32, device=dev)
+            fc = torch.empty((frames.shape[0], chunk, C, H, W), dtype=torch.float32, device=dev) if continous else None
+            self.denoise_fn.ready()
+            eng.sample(xc.data_ptr() if xc is not None else None, chunk, H, W, oc.data_ptr(),
+                       nc.data_ptr() if nc is not None else None, seed, image_offset + a,
+                       fc.data_ptr() if fc is not None else None)
+            self.denoise_fn.finish()
+            if not whole:
+                out[a:b] = oc[: b - a]
+            if continous:
+                frames[:, a:b] = fc[:, : b - a]
         return (out, frames) if continous else out
 
     @torch.no_grad()
@@ -149,9 +195,9 @@ class GaussianDiffusion(nn.Module):
         return self.p_sample_loop(x_in, continous)
 
     @torch.no_grad()
-    def super_resolution_batch(self, x_in, noise=None, seed=None, image_offset=0):
-        """Throughput entry point: every image of the batch, [B,3,H,W]."""
-        return self.sample_batch(x_in, False, noise, seed, image_offset)
+    def super_resolution_batch(self, x_in, noise=None, seed=None, image_offset=0, max_chunk=None):
+        """Throughput entry point: every image of the batch, [B,3,H,W] (any B: see sample_batch)."""
+        return self.sample_batch(x_in, False, noise, seed, image_offset, max_chunk)
 
     @torch.no_grad()
     def p_sample(self, x, t, clip_denoised=True, condition_x=None, noise=None):
@@ -173,23 +219,32 @@ class GaussianDiffusion(nn.Module):
             eng.sample_step(int(t), nz.data_ptr() if nz is not None else None)
             eng.sample_end(out.data_ptr())
 
+        # The step API cannot replay inside the library (the caller owns the noise); this facade still holds x, cond and
+        # noise, so it finishes the step like sr3_sample would: an in-place split-K wait that gave up -> the same step again
+        # (the library has switched to its non-waiting conv path); an out-of-range step -> one arithmetic down, f16f8 ->
+        # f16x3 -> exact f32 (the reference computes in fp32 and has no range limit, unet.py:235-265).
+        import warnings
+        from ._lib import Sr3RangeWarning, Sr3ReplayWarning
+        prev = getattr(eng, "precision", "f32")
+        ladder = {"f16f8": ["f16x3", "f32"], "f16x3": ["f32"], "f32": []}[prev]
         try:
-            one_step()
-        except Sr3Error as e:
-            # the step API cannot replay inside the library (the caller owns the noise); this facade still holds
-            # x, cond and noise, so an out-of-range split-f16 step is evaluated again in exact f32 — the
-            # reference computes in fp32 and has no range limit (unet.py:235-265)
-            prev = getattr(eng, "precision", "f32")
-            if "fp16 range" not in str(e) or prev == "f32" or self.denoise_fn.strict_range:
-                raise
-            import warnings
-            from ._lib import Sr3RangeWarning
-            eng.set_precision("f32")
-            try:
-                one_step()
-            finally:
+            for attempt in range(8):
+                try:
+                    one_step()
+                    break
+                except Sr3Error as e:
+                    msg = str(e)
+                    if "repeat the call" in msg and attempt == 0:
+                        warnings.warn(Sr3ReplayWarning(f"p_sample(t={int(t)}) repeated: {e}"), stacklevel=2)
+                        continue
+                    if "range" not in msg or not ladder or self.denoise_fn.strict_range:
+                        raise
+                    nxt = ladder.pop(0)
+                    eng.set_precision(nxt)
+                    warnings.warn(Sr3RangeWarning(f"p_sample(t={int(t)}) recomputed in {nxt}: {e}"), stacklevel=2)
+        finally:
+            if getattr(eng, "precision", prev) != prev:
                 eng.set_precision(prev)
-            warnings.warn(Sr3RangeWarning(f"p_sample(t={int(t)}) recomputed in exact f32: {e}"), stacklevel=2)
         self.denoise_fn.finish()
         return out
 

@@ -70,18 +70,47 @@ def all_gather_images(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)], dim=0)
 
 
+def _local_shard(x_full: torch.Tensor):
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    return shard_bounds(x_full.shape[0], world, rank)
+
+
 def sharded_super_resolution(sample_fn: Callable[[torch.Tensor, int], torch.Tensor],
                              x_full: torch.Tensor, gather: bool = True) -> torch.Tensor:
     """Runs `sample_fn(x_local, image_offset)` on this rank's slice of `x_full` [N,3,H,W] and
     all-gathers the results. `sample_fn` is `lambda x, off: netG.super_resolution_batch(x,
-    seed=seed, image_offset=off)` in production."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    a, b = shard_bounds(x_full.shape[0], world, rank)
+    seed=seed, image_offset=off)` in production.
+
+    Stream ordering: the result must be ordered on torch's CURRENT stream of its device when `sample_fn` returns — the
+    torch facade guarantees it (UNet.finish(): torch's stream waits on the device for the library's stream, an event,
+    no host stall), and the collective is enqueued behind that stream like any torch operation. A `sample_fn` built on
+    a raw `Engine` calls `eng.stream_wait_for_engine(torch.cuda.current_stream().cuda_stream)` itself. No host
+    synchronisation happens here."""
+    a, b = _local_shard(x_full)
     local = sample_fn(x_full[a:b], a)
-    if local.is_cuda:
-        # explicit dependency before the collective: the sampler may have run on the library's own
-        # stream, which RCCL's stream does not wait for (the torch facade already waits for it; a raw
-        # Engine-based sample_fn may not): wait for every stream of this device, once per call
-        torch.cuda.synchronize(local.device)
     return all_gather_images(local, x_full.shape[0]) if gather else local
+
+
+def sharded_p_sample_loop(netG, x_full: torch.Tensor, continous: bool = False, seed: int = 0) -> torch.Tensor:
+    """The reference's `super_resolution(x_in, continous)` (diffusion.py:189-215, 223-225) for a batch sharded over the
+    ranks, with the reference's return convention on EVERY rank:
+
+      continous=False -> `ret_img[-1]`: the LAST image of the global batch, [3,H,W]
+      continous=True  -> `ret_img` = cat([x_in, frame_0, ..., frame_9]) on dim 0, [(1 + n_frames) * N, 3, H, W], the
+                         conditioning batch first (:203-204), then the whole batch after every recorded step (:209-211)
+
+    Two collectives at most: the final images (N/world x 3 x r x r per rank) and, if continous, the frames (n_frames
+    times as much: 126 MB per rank for 256 images at 128x128 — still one call). `seed` must be the same on every rank
+    (Philox streams are keyed by the global image index)."""
+    N = x_full.shape[0]
+    a, b = _local_shard(x_full)
+    x_loc = x_full[a:b].to(next(netG.parameters()).device)
+    if not continous:
+        out = all_gather_images(netG.super_resolution_batch(x_loc, seed=seed, image_offset=a), N)
+        return out[-1]
+    out, frames = netG.sample_batch(x_loc, True, None, seed, a)            # frames [n, b_local, C, H, W]
+    # gather along the image axis: put it first, one collective, back
+    fr = all_gather_images(frames.transpose(0, 1).contiguous(), N)       # [N, n, C, H, W]
+    fr = fr.transpose(0, 1).reshape(-1, *frames.shape[2:])               # [n * N, C, H, W], frame-major like ret_img
+    return torch.cat([x_full.to(device=fr.device, dtype=torch.float32), fr], dim=0)

@@ -119,6 +119,10 @@ class Engine:
     def fallback_calls(self) -> int:
         return int(self.lib.sr3_fallback_calls(self.ctx))
 
+    def replay_calls(self) -> int:
+        """Calls finished after replaying work whose in-place split-K wait had given up (SR3_OK_REPLAYED)."""
+        return int(self.lib.sr3_replay_calls(self.ctx))
+
     def synchronize(self):
         _lib.check(self.lib.sr3_synchronize(self.ctx))
 
@@ -176,6 +180,13 @@ class Engine:
 
     def num_frames(self) -> int:
         n = self.lib.sr3_num_frames(self.ctx)
+        if n < 0:
+            _lib.check(n)
+        return n
+
+    def max_batch(self, H: int, W: int) -> int:
+        """Largest batch one sample / unet_forward call takes at H x W (4 GiB per activation tensor)."""
+        n = self.lib.sr3_max_batch(self.ctx, int(H), int(W))
         if n < 0:
             _lib.check(n)
         return n

@@ -68,6 +68,8 @@ def validate_batch(netG, sr: "torch.Tensor", hr: "torch.Tensor", samples: int = 
     images (sample k of image i is batch row k*N + i) and scores them against `hr`.
 
     sr, hr: [N,3,r,r] in [-1,1] (the dataset's 'SR' and 'HR' entries, datasets/LRHR_dataset.py:93-99).
+    N * samples may exceed what one library call takes (~250 images at 128x128): `sample_batch` runs equal chunks
+    with the Philox streams keyed by the global row, so the scores do not depend on the chunking.
     Returns per (sample, image) PSNR / SSIM arrays and their means. The reference's running
     `avg / idx * sample` (lib/trainer_temp.py:445-446) multiplies by `sample` instead of dividing —
     the plain means are reported here.

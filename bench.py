@@ -15,19 +15,26 @@ Inputs are resident in HBM before the timed region. Multi-GPU: the batch is shar
 scaling, 64 images per GPU), no collective inside the loop, one RCCL all-gather of the finished
 images at the end of the timed region.
 
+The headline (`value`, `ms_per_step`, `dtype`, `roofline`) is measured in the REFERENCE's arithmetic: fp32 operands,
+fp32 accumulation (`--precision f32`, v_mfma_f32_32x32x2_f32; reference unet.py:235-265 / diffusion.py:164-187 compute
+in plain fp32). The library's faster split-f16 arithmetics are reported next to it, never as `value`.
+
 The JSON line also carries
-  roofline     the conv implicit-GEMM kernel family: algorithmic FLOPs / HIP-event time per launch
-               against the dense MFMA peak of the mode's instruction — 2500 TFLOP/s (f16 MFMA) in the
-               split-f16 modes (the default f16f8 is priced against the f16 peak too, although a third of its
-               conv work issues half of its MFMA cycles on the fp8 path), 157.3 TFLOP/s (f32-input MFMA) with
-               --precision f32 — plus `executed_frac`: the MFMA work issued in f16x3 accounting (3 MFMA MACs per
-               product, 16/36 of the MACs on the sub-pixel Upsample convs) over the same peak
-  alt_precisions  the other arithmetic modes of the same library measured in the same run (exact f32; f16x3)
-  full_loop    ONE whole sr3_sample call (T steps, intermediate frames recorded) timed end to end:
-               the sustained rate next to the K-step figure
+  roofline     the conv implicit-GEMM kernel family of the headline mode: algorithmic FLOPs / HIP-event time per
+               launch against the dense MFMA peak of the mode's instruction — 157.3 TFLOP/s (f32-input MFMA) for f32,
+               2500 TFLOP/s (f16 MFMA) for the split-f16 modes (f16f8 is priced against the f16 peak too) — plus
+               `executed_frac` (MFMA work issued: 3 MFMA MACs per product in f16x3, 16/36 of the MACs on the sub-pixel
+               Upsample convs) and `traffic` (HBM bytes per conv launch from the committed PMC summary of that mode)
+  alt_precisions  one FULL block per other arithmetic mode of the same library measured in the same run: ms per step,
+               img/s, its own `roofline` object and its own `parity` (below)
+  parity       max-abs of the GPU against the CPU oracle on the cpu_baseline sample, with the sample REPLICATED to the
+               benchmark batch (B = 64) so that every mode runs the kernels it runs in the timed region (f16f8 takes
+               its fp8 path only at full batch); every replica is compared
+  full_loop    ONE whole sr3_sample call (T steps, intermediate frames recorded) timed end to end in the headline
+               mode (and in the fastest alternative mode): the sustained rate next to the K-step figure;
+               `fallback_calls` must stay 0 (no range-policy replay hidden in the figure)
   cpu_baseline oracle/sr3_oracle_aten.py (the build's restatement on torch's CPU operators — what the
-               reference's CPU path runs on) timed on this host on a bounded sample ("port-aten"), and the
-               GPU-vs-oracle parity of that same sample.
+               reference's CPU path runs on) timed on this host on a bounded sample ("port-aten").
 """
 import argparse
 import importlib
@@ -48,7 +55,7 @@ sys.path.insert(0, ROOT)
 
 # MI355X_MICROARCH.md, dense peaks: v_mfma_f32_32x32x2_f32 (= f32 vector peak) and f16/bf16 MFMA
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16f8": 2500.0}      # (f16f8 priced against the f16 peak too)
-DTYPE = {"f32": "f32", "f16x3": "f16x3-split (hi+lo fp16 operands, 3 MFMA per product, fp32 accumulate)",
+DTYPE = {"f32": "f32 (fp32 operands, fp32 accumulate: the reference's arithmetic)", "f16x3": "f16x3-split (hi+lo fp16 operands, 3 MFMA per product, fp32 accumulate)",
          "f16f8": "f16x3-split with the two correction products of the 32x32 / 16x16-pixel convs on the fp8 MFMA (e4m3, fp32 accumulate)"}
 
 
@@ -62,9 +69,10 @@ def parse():
     ap.add_argument("--lres", type=int, default=16)
     ap.add_argument("--T", type=int, default=1000, help="diffusion steps per image (BASELINE configs[1]: 1000)")
     ap.add_argument("--image-size", type=int, default=224, help="UNet image_size key: 224 = yml-literal, 128 = 6 attention modules")
-    ap.add_argument("--precision", default="f16f8", choices=["f32", "f16x3", "f16f8"],
-                    help="conv arithmetic: exact f32 MFMA, or split-f16 (fp32-equivalent accuracy, default)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the secondary measurement of the other precision")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16f8"],
+                    help="arithmetic of the HEADLINE: f32 = the reference's (default); the split-f16 modes are "
+                         "reported as alt_precisions")
+    ap.add_argument("--no-alt", action="store_true", help="skip the measurement of the other arithmetic modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the timed whole-loop sr3_sample call (N=1 only)")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -72,8 +80,9 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
-    """CPU baseline on a bounded sample of the same workload + parity of the GPU on that sample.
+def cpu_baseline(cfg, sd, sched_opt, args, synth):
+    """CPU baseline on a bounded sample of the same workload. Returns (record, sample) where `sample` holds the
+    inputs and the CPU result so that every GPU arithmetic mode can be checked against it (gpu_parity).
 
     The timed code is oracle/sr3_oracle_aten.py: the build's own restatement of the reference's sampler on torch's
     CPU operators (F.conv2d / F.group_norm / bmm) — the operator library the reference's CPU path itself runs on
@@ -82,7 +91,6 @@ def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import sr3_oracle_aten as aten      # checker / baseline only
-    metrics = importlib.import_module(PKG + ".metrics")
     B, r, T, K = args.cpu_batch, args.res, args.T, args.cpu_steps
     cond = synth.synth_cond(B, r, args.lres, 4242)
     noise = synth.synth_noise(K + 1, B, 3, r, r, 4242)
@@ -109,15 +117,6 @@ def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
         for k in range(K):
             x = aten.p_sample(tsd, cfg, sch, x, T - 1 - k, tc, torch.from_numpy(noise[k + 1].copy()))
         dt = time.perf_counter() - t0
-    x = x.numpy()
-    # the same K steps on the GPU with the same injected noise
-    dc, dn, out = eng.to_device(cond), eng.to_device(noise), eng.buffer(B * 3 * r * r)
-    slab = B * 3 * r * r * 4
-    eng.sample_begin(dc.ptr, B, r, r, dn.ptr)
-    for k in range(K):
-        eng.sample_step(T - 1 - k, dn.ptr + (k + 1) * slab)
-    eng.sample_end(out.ptr)
-    got = out.download((B, 3, r, r))
     base = {
         "value": B / (T * dt / K), "unit": "img/s", "cores": int(threads), "kind": "port-aten",
         "host_cpus": os.cpu_count(), "thread_trials_s_per_step": {str(k): round(v, 3) for k, v in trial.items()},
@@ -127,25 +126,63 @@ def cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth):
                        "0.25 s per image-step at 128x128 => ~0.004 img/s at T=1000 (BASELINE.md section 2); "
                        "the reference itself cannot run on the GPU box"),
     }
-    st = metrics.batch_psnr_stats(got, x)
+    return base, {"cond": cond, "noise": noise, "want": x.numpy(), "K": K}
+
+
+def gpu_parity(eng, torch, sample, args, precision, batch):
+    """The CPU sample's K steps on the GPU in `precision`, with the sample replicated to `batch` images (replica j of
+    sample image i is batch row j * b + i, same injected noise) so that the kernels of the timed region run — the
+    f16f8 mode takes its fp8 path only where conv_f8_supported(batch, ...) — and EVERY replica is compared."""
+    metrics = importlib.import_module(PKG + ".metrics")
+    cond, noise, want, K = sample["cond"], sample["noise"], sample["want"], sample["K"]
+    b, r, T = cond.shape[0], args.res, args.T
+    rep = max(1, batch // b)
+    B = rep * b
+    dc = torch.from_numpy(cond).cuda().repeat(rep, 1, 1, 1).contiguous()
+    dn = torch.from_numpy(noise).cuda().repeat(1, rep, 1, 1, 1).contiguous()     # [K+1][B][3][r][r]
+    out = torch.empty((B, 3, r, r), dtype=torch.float32, device="cuda")
+    prev = eng.precision
+    eng.set_precision(precision)
+    fb0 = eng.fallback_calls()
+    torch.cuda.synchronize()
+    slab = B * 3 * r * r * 4
+    eng.sample_begin(dc.data_ptr(), B, r, r, dn.data_ptr())
+    for k in range(K):
+        eng.sample_step(T - 1 - k, dn.data_ptr() + (k + 1) * slab)
+    eng.sample_end(out.data_ptr())
+    eng.synchronize()
+    got = out.cpu().numpy().reshape(rep, b, 3, r, r)
+    eng.set_precision(prev)
+    err = np.abs(got - want[None]).max(axis=(1, 2, 3, 4))          # per replica
+    st = metrics.batch_psnr_stats(got.reshape(B, 3, r, r), np.tile(want, (rep, 1, 1, 1)))
     # psnr_db: mean over the images that differ after uint8 rounding (null if none differs — JSON has
     # no Infinity); identical_after_rounding counts the images whose PSNR is infinite
-    parity = {"max_abs": float(np.abs(got - x).max()), "psnr_db": st["mean_db"],
-              "identical_after_rounding": st["identical"], "images": st["n"], "steps": K, "tolerance": 1e-3}
-    return base, parity
+    return {"max_abs": float(err.max()), "max_abs_best_replica": float(err.min()), "batch": B, "replicas": rep,
+            "psnr_db": st["mean_db"], "identical_after_rounding": st["identical"], "images": st["n"], "steps": K,
+            "tolerance": 1e-3, "vs": "oracle/sr3_oracle_aten.py on the cpu_baseline sample",
+            "fallback_calls": eng.fallback_calls() - fb0}
 
 
-def full_loop(eng, torch, B, r, T, cond, sec_per_step):
+def full_loop(eng, torch, B, r, T, cond, sec_per_step, precision):
     """One whole p_sample_loop through sr3_sample (T steps, frames recorded like continous=True)."""
     out = torch.empty((B, 3, r, r), dtype=torch.float32, device="cuda")
     frames = torch.empty((eng.num_frames(), B, 3, r, r), dtype=torch.float32, device="cuda")
+    prev = eng.precision
+    eng.set_precision(precision)
+    fb0 = eng.fallback_calls()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.sample(cond.data_ptr(), B, r, r, out.data_ptr(), None, 7, 0, frames.data_ptr())
     eng.synchronize()
     dt = time.perf_counter() - t0
+    fb = eng.fallback_calls() - fb0
+    eng.set_precision(prev)
     ok = bool(torch.isfinite(out).all().item()) and float(out.abs().max().item()) <= 1.0
-    return {"seconds": dt, "img_per_s": B / dt, "T": T, "frames": int(frames.shape[0]), "batch": B,
+    # a range-policy replay (f16f8 -> f16x3 -> f32 segments) would be correct but slower and would make this figure a
+    # mixture of arithmetics: it must not happen silently
+    assert fb == 0, f"full_loop in {precision}: {fb} range-policy fallback(s) inside the timed call"
+    return {"precision": precision, "fallback_calls": fb,
+            "seconds": dt, "img_per_s": B / dt, "T": T, "frames": int(frames.shape[0]), "batch": B,
             "ms_per_step": dt / T * 1e3,
             "vs_step_extrapolation_pct": 100.0 * (dt / (T * sec_per_step) - 1.0),
             "finite_and_clamped": ok,
@@ -247,64 +284,61 @@ def main():
             assert torch.equal(gathered, out), "world-size-1 all-gather must be the identity"
     sec_per_step = dt / K
 
-    # ---- roofline of the dominant kernel family (rank 0): same K steps, HIP events per launch
-    roof = None
-    if rank == 0:
+    # ---- per-mode blocks (rank 0): the headline mode first, then the other arithmetic modes of the same library
+    def roofline_block(precision, steps, t_from, sec_step):
+        """Conv family of `precision`: the same `steps` steps again with a HIP-event pair around every launch (events
+        on the library's stream; a second pass so that event overhead never touches `value`)."""
         eng.profile_reset()
         eng.profile_enable(True)
-        run_steps(K, t_next)
+        t_after = run_steps(steps, t_from)
         prof = eng.profile_get()
-        if os.environ.get("SR3_PROFILE_CSV"):
+        if os.environ.get("SR3_PROFILE_CSV") and precision == args.precision:
             eng.profile_dump_csv(os.environ["SR3_PROFILE_CSV"])
         eng.profile_enable(False)
         conv = prof["conv_igemm"]
         n = max(1, conv["launches"])
-        avg_ms = conv["ms"] / n
-        achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-        total_ms = sum(v["ms"] for v in prof.values())
-        peak = PEAK_TFLOPS[args.precision]
+        sec = conv["ms"] * 1e-3
+        achieved = conv["flops"] / sec / 1e12 if sec > 0 else 0.0
+        peak = PEAK_TFLOPS[precision]
         # MFMA work actually issued by the family: the sub-pixel Upsample convs execute 16/36 of their
         # algorithmic MACs, split-f16 issues 3 MFMA MACs per executed product
-        up_alg = graph.upsample_flops_per_image(cfg, r, r) * B * K
-        executed = (conv["flops"] - up_alg * (20.0 / 36.0)) * (1.0 if args.precision == "f32" else 3.0)
+        up_alg = graph.upsample_flops_per_image(cfg, r, r) * B * steps
+        executed = (conv["flops"] - up_alg * (20.0 / 36.0)) * (1.0 if precision == "f32" else 3.0)
         f8c_alg = 0.0
-        if args.precision == "f16f8":
+        if precision == "f16f8":
             # convs on the fp8 correction path issue 2/3 of f16x3's MFMA cycles (two f16 MFMAs + one fp8 MFMA of twice the
             # cycles instead of six): counted in f16-MFMA cycle equivalents
             f8c_alg = sum(2.0 * hh * ww * co * ci * 9 for hh, ww, ci, co in graph.resblock_conv3x3_shapes(cfg, r, r)
-                          if eng.conv_f8_supported(B, hh, ww, co, ci)) * B * K
+                          if eng.conv_f8_supported(B, hh, ww, co, ci)) * B * steps
             executed -= f8c_alg
-        roof_f8c_share = f8c_alg / conv["flops"] if conv["flops"] else 0.0
-        roof = {
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak,
-            "executed_frac": (executed / (conv["ms"] * 1e-3) / 1e12) / peak if conv["ms"] > 0 else 0.0,
-            "executed_mfma_tflops": executed / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0,
-            "f8c_flop_share": roof_f8c_share,
-            "traffic": (pmc_traffic(args.precision) / (n / K)) if pmc_traffic(args.precision) else None,
-            "note": ("achieved = algorithmic conv FLOPs (the reference's conv arithmetic, SURVEY 8d) / HIP-event "
-                     "time per logical conv; the Upsample convs execute 16/36 of their algorithmic MACs (sub-pixel "
-                     "phases). " +
-                     ("In f16x3 every executed MAC costs 3 MFMA MACs (matrix-pipe busy: see profiles/README.md)."
-                      if args.precision == "f16x3" else
-                      ("executed_* in f16-MFMA cycle equivalents: 3 per product, 2 per product in the convs on the fp8 correction "
-                       "path (f8c_flop_share of the family's algorithmic FLOPs)."
-                       if args.precision == "f16f8" else "Exact-f32 MFMA."))),
+        traffic = pmc_traffic(precision)
+        note = {"f32": "Exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the reference's arithmetic.",
+                "f16x3": "Every executed MAC costs 3 f16 MFMA MACs (hi*hi + hi*lo + lo*hi); matrix-pipe busy: profiles/README.md.",
+                "f16f8": ("executed_* in f16-MFMA cycle equivalents: 3 per product, 2 per product in the convs on the fp8 "
+                          "correction path (f8c_flop_share of the family's algorithmic FLOPs).")}[precision]
+        return t_after, {
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": (traffic / (n / steps)) if traffic else None,
+            "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC summary profiles/pmc_latest_%s.json)" % precision,
+            "executed_frac": (executed / sec / 1e12) / peak if sec > 0 else 0.0,
+            "executed_mfma_tflops": executed / sec / 1e12 if sec > 0 else 0.0,
+            "f8c_flop_share": f8c_alg / conv["flops"] if conv["flops"] else 0.0,
+            "note": ("achieved = algorithmic conv FLOPs (the reference's conv arithmetic, SURVEY 8d) / HIP-event time per "
+                     "logical conv; the Upsample convs execute 16/36 of their algorithmic MACs (sub-pixel phases). " + note),
             "kernel": "conv family: conv3x3_halo_h3<...> + conv_igemm_dma_f32<...> (all tile shapes)",
-            "launches_per_step": n / K,
-            "avg_launch_ms": avg_ms, "flop_per_launch": conv["flops"] / n,
-            "family_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
-            "whole_step_frac": (B * graph.flops_per_image(cfg, r, r) / sec_per_step / 1e12) / peak,
-            "event_timed_step_ms": total_ms / K,
+            "launches_per_step": n / steps, "avg_launch_ms": conv["ms"] / n, "flop_per_launch": conv["flops"] / n,
+            "family_ms_per_step": {k: v["ms"] / steps for k, v in prof.items()},
+            "whole_step_frac": (B * graph.flops_per_image(cfg, r, r) / sec_step / 1e12) / peak,
+            "event_timed_step_ms": sum(v["ms"] for v in prof.values()) / steps,
         }
 
-    alt = None
+    roof = None
     alts = {}
+    if rank == 0:
+        t_next, roof = roofline_block(args.precision, K, t_next, sec_per_step)
     if rank == 0 and not args.no_alt:
-        # the other arithmetic modes of the same library on the same box: exact f32 always; f16x3 next to f16f8
-        others = ["f32"] if args.precision == "f16x3" else (["f32", "f16x3"] if args.precision == "f16f8" else ["f16x3", "f16f8"])
         t_a = t_next
-        for other in others:
+        for other in [m for m in ("f32", "f16x3", "f16f8") if m != args.precision]:
             eng.set_precision(other)
             t_a = run_steps(max(1, W), t_a)
             torch.cuda.synchronize()
@@ -312,38 +346,41 @@ def main():
             t_a = run_steps(K, t_a)
             torch.cuda.synchronize()
             sa = (time.perf_counter() - ta0) / K
-            eng.profile_reset(); eng.profile_enable(True)
-            run_steps(min(K, 5), t_a)
-            pa = eng.profile_get()["conv_igemm"]
-            eng.profile_enable(False)
-            alts[other] = {"precision": other, "ms_per_step": sa * 1e3, "img_per_s_1gpu": B / (T * sa),
-                           "conv_tflops": pa["flops"] / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] else 0.0,
-                           "conv_frac_of_peak": (pa["flops"] / (pa["ms"] * 1e-3) / 1e12) / PEAK_TFLOPS[other] if pa["ms"] else 0.0}
-        alt = alts[others[0]]
+            t_a, ra = roofline_block(other, min(K, 10), t_a, sa)
+            alts[other] = {"precision": other, "dtype": DTYPE[other], "ms_per_step": sa * 1e3,
+                           "img_per_s_1gpu": B / (T * sa), "roofline": ra}
         eng.set_precision(args.precision)
     if rank == 0:
+        lo_hi = f"{args.lres}->{r}"
         res = {
-            "metric": "SR images/sec (full p_sample_loop, 16->128)",
+            "metric": f"SR images/sec (full p_sample_loop, {lo_hi})",
             "value": world * B / (T * sec_per_step), "unit": "img/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE[args.precision], "data": "synthetic",
+            "dtype": DTYPE[args.precision], "precision": args.precision, "data": "synthetic",
             "config": {"workload": f"sr_sr3_VGGF2_{args.lres}_{r} p_sample_loop, yml UNet image_size={args.image_size}",
                        "batch_per_gpu": B, "global_batch": B * world, "T": T,
                        "gflop_per_image_step": graph.flops_per_image(cfg, r, r) / 1e9,
                        "step": "one p_sample step (UNet forward + DDPM update) over the per-GPU batch",
+                       "stages_not_run": ("BASELINE configs[4]'s MICA / FLAME stage is outside this path (SURVEY 8: untouched "
+                                          "PyTorch encoder; FLAME assets and loguru absent): SR stage only"),
                        "parallelism": f"batch-sharded x{world}, one all-gather at the end" +
                                       (" (SR3_FORCE_COLLECTIVE: world-size-1 RCCL all-gather executed)" if collective and world == 1 else "")},
             "roofline": roof,
-            "alt_precision": alt,
             "alt_precisions": alts,
         }
         if world == 1 and not args.no_full_loop:
-            res["full_loop"] = full_loop(eng, torch, B, r, T, cond, sec_per_step)
+            res["full_loop"] = full_loop(eng, torch, B, r, T, cond, sec_per_step, args.precision)
+            if alts:
+                fastest = min(alts, key=lambda m: alts[m]["ms_per_step"])
+                alts[fastest]["full_loop"] = full_loop(eng, torch, B, r, T, cond, alts[fastest]["ms_per_step"] * 1e-3, fastest)
         if not args.no_cpu_baseline and world == 1:
-            base, parity = cpu_baseline_and_parity(eng, cfg, sd, sched_opt, args, synth)
+            base, sample = cpu_baseline(cfg, sd, sched_opt, args, synth)
             res["cpu_baseline"] = base
-            res["parity"] = parity
+            res["parity"] = dict(gpu_parity(eng, torch, sample, args, args.precision, B), precision=args.precision)
+            for m in alts:
+                alts[m]["parity"] = gpu_parity(eng, torch, sample, args, m, B)
+        res["fallback_calls"] = eng.fallback_calls()
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res, allow_nan=False) + "\n").encode())
     if collective:

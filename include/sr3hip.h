@@ -59,6 +59,14 @@ const char *sr3_last_error(void);
  * the call's result is complete and valid, but the split-f16 arithmetic left its range and (part of) the
  * call was recomputed in exact f32 — message via sr3_last_warning(). See sr3_set_range_policy. */
 #define SR3_OK_F32_FALLBACK 1
+/* ... and a second one: the result is complete and valid, but part of the call was REPLAYED in the same arithmetic on
+ * another kernel path. Cause: the in-place split-K convs (deep-K convs over few tiles — the 8x8 level at B = 64) let the
+ * blocks of one output tile wait for each other; that needs a free CU slot for each of them, which an otherwise idle GPU
+ * always has. If another kernel (another stream or process: e.g. the ArcFace encoder that follows the SR stage,
+ * model/sr3d/model.py:372-393) holds those slots, the bounded wait (5 ms) gives up, the work is replayed on the path
+ * without inter-block waits and the context stays on that path. Never a hang, never a failed call.
+ * sr3_replay_calls counts them; SR3_HALO_SPLITS=0 in the environment selects the non-waiting path from the start. */
+#define SR3_OK_REPLAYED 2
 const char *sr3_last_warning(void);
 /* work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream) */
 int sr3_set_stream(sr3_ctx *ctx, void *hip_stream);
@@ -131,6 +139,11 @@ int sr3_set_schedule(sr3_ctx *ctx, int T, const float *noise_level, const float 
 int sr3_sample(sr3_ctx *ctx, const float *cond_dev, int B, int H, int W, const float *noise_dev,
                uint64_t seed, uint64_t image_offset, float *out_dev, float *frames_dev);
 int sr3_num_frames(sr3_ctx *ctx);
+/* Largest batch ONE sr3_sample / sr3_unet_forward call takes at H x W (every activation tensor below 4 GiB: 32-bit DMA
+ * offsets; ~250 images at 128x128 with the yml UNet). Larger batches — the reference's validation loop is 15 samples x N
+ * images, lib/trainer_temp.py:441-446; BASELINE configs[3] is 512 images — are run as equal chunks with image_offset
+ * advancing, which the Python facade does by itself (GaussianDiffusion.sample_batch). < 0: error. */
+int sr3_max_batch(sr3_ctx *ctx, int H, int W);
 /* One p_sample step t on the library-resident state (used by bench.py to time exact step counts):
  * sr3_sample_begin loads cond + initial noise, sr3_sample_step runs step t, sr3_sample_end copies
  * the current image out. noise_slab_dev may be NULL (Philox). */
@@ -153,10 +166,20 @@ int sr3_sample_end(sr3_ctx *ctx, float *out_dev);
  *     and the message names the f32 mode as the remedy.
  *   sr3_sample_end (step API: the caller owns the noise slabs, the library cannot replay) always
  *     fails on overflow; sr3_range_check does the same on demand between sr3_sample_step calls:
- *     0 = in range, < 0 = overflow since the last check (flag cleared). Both synchronise the stream. */
+ *     0 = in range, < 0 = overflow since the last check (flag cleared). Both synchronise the stream.
+ *   In mode 2 ("f16f8") the flag is also raised by an activation beyond the fp8 operand range (|v| > 448) in a conv on
+ *     the fp8 correction path; the message then names mode 1 (f16x3) as the first remedy, mode 0 as the second, and the
+ *     default policy of sr3_unet_forward / sr3_sample retries in exactly that order.
+ *   The same flag word carries the "in-place split-K wait gave up" bit (SR3_OK_REPLAYED above): sr3_unet_forward and
+ *     sr3_sample replay by themselves; sr3_sample_end / sr3_range_check fail with a message that says to repeat the call. */
 int sr3_range_check(sr3_ctx *ctx);
 int sr3_set_range_policy(sr3_ctx *ctx, int strict);
 int sr3_fallback_calls(sr3_ctx *ctx);
+int sr3_replay_calls(sr3_ctx *ctx);
+/* TEST HOOK (tests/test_gpu_round4.py): device address of the context's flag word (bit 0: range overflow, bit 1: an
+ * in-place split-K wait gave up), so that a test kernel on another stream can raise a bit in the middle of a running
+ * sr3_sample call and the replay logic is exercised deterministically. Not for production use. */
+void *sr3_test_flag_address(sr3_ctx *ctx);
 
 /* The documented CPU twin of the device RNG is oracle/philox.py; this dumps the device stream for
  * comparison: n floats of draw `draw` for image `image`. */

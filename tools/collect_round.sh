@@ -10,7 +10,7 @@ python tools/step_profile.py --batch 64 --steps 20 --precision f16f8 --csv gpuru
 python tools/step_profile.py --batch 64 --steps 20 --precision f16x3 --csv gpurun_out/conv_shapes_f16x3.csv >> gpurun_out/sp64.txt 2>&1
 python bench.py > gpurun_out/bench_full.log 2>&1
 : > gpurun_out/configs.txt
-run_cfg() { echo "== bench.py $*" >> gpurun_out/configs.txt; python bench.py "$@" --no-alt --no-cpu-baseline 2>/dev/null | tail -n 1 >> gpurun_out/configs.txt; }
+run_cfg() { echo "== bench.py $*" >> gpurun_out/configs.txt; python bench.py "$@" --no-cpu-baseline 2>/dev/null | tail -n 1 >> gpurun_out/configs.txt; }
 run_cfg --batch 4 --res 16 --lres 8 --T 100 --steps 100
 run_cfg --image-size 128
 run_cfg --lres 8
