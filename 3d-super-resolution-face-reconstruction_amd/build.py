@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsr3hip.so")
-SOURCES = ["sr3_api.hip", "kernels_conv.hip", "kernels_misc.hip", "kernels_edge.hip", "kernels_pre.hip", "kernels_post.hip"]
+SOURCES = ["sr3_api.hip", "kernels_conv.hip", "kernels_conv_ws.hip", "kernels_misc.hip", "kernels_edge.hip", "kernels_pre.hip", "kernels_post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source flags: the fp32 VALU contraction of kernels_edge.hip must stay scalar v_fma_f32 (the SLP
 # vectoriser packs it into v_pk_fma_f32 pairs: register-pair shuffles, 2 KB of scratch per lane)

@@ -2587,6 +2587,10 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
+        // 64 -> 64 channels over many 128-pixel tiles (the full-resolution level): weights-stationary persistent kernel
+        if (p.stats == nullptr || p.stats_slices == (p.Hout * p.Wout) / 128) {
+            if (!halo_off() && conv_ws_supported(p)) { launch_conv_ws(p, s); break; }
+        }
         if (halo_ok(p, 128, 32, 64)) {
 #ifdef SR3_EXPERIMENTS
             if (halo_mfma16() && halo_persistent() && p.ks == 3) launch_halo_pt<128, 64, 32, 3>(p, s);

@@ -1124,6 +1124,8 @@ void enqueue_step(sr3_ctx *c) {
 int step_impl(sr3_ctx *c, int t, const float *noise_slab, float *frame) {
     if (!c->sampling) return fail("sr3_sample_step before sr3_sample_begin");
     if (t < 0 || t >= c->T) return fail("step t=%d outside schedule of %d steps", t, c->T);
+    // (the arithmetic mode may have been switched between steps: the F8C weight copies are made on demand)
+    if (c->f8corr && c->f8_dirty && prepare_f8(c)) return -1;
     if (!c->h_ring) {
         HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&c->h_ring), sizeof(StepArgs) * sr3_ctx::kRing, hipHostMallocDefault));
         HIP_OK(hipMalloc(&c->d_step, sizeof(StepArgs)));

@@ -175,6 +175,10 @@ void launch_conv(const ConvParams &p, hipStream_t s);
 // launch_conv never aborts the process: a request it cannot honour (a caller / library bug) launches nothing and leaves
 // a message here; returns it once (nullptr if none) — the C-ABI entry points fail the call with it
 const char *conv_take_error();
+// weights-stationary kernel for the 64 -> 64 channel 3x3 convs of the full-resolution level (kernels_conv_ws.hip):
+// launch_conv takes it where conv_ws_supported says so (p as launch_conv sees it: hw_shift / w_shift set)
+bool conv_ws_supported(const ConvParams &p);
+void launch_conv_ws(const ConvParams &p, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
 // parity (py, px) see only a 2x2 window of the low-resolution input, with the 3x3 taps that land
 // on the same source pixel pre-added (make_up2_phase_weights) — 16 instead of 36 MACs per

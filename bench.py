@@ -117,6 +117,12 @@ def cpu_baseline(cfg, sd, sched_opt, args, synth):
         for k in range(K):
             x = aten.p_sample(tsd, cfg, sch, x, T - 1 - k, tc, torch.from_numpy(noise[k + 1].copy()))
         dt = time.perf_counter() - t0
+        # one UNet evaluation (diffusion.py:170) mid-schedule on the same inputs: the denoiser's own output, before the
+        # clamp of the update step (which hides most of an arithmetic's error in the first steps of a chain)
+        t_mid = T // 2
+        nl_mid = float(np.float32(sch["sqrt_alphas_cumprod_prev"][t_mid + 1]))
+        eps_want = aten.unet_forward(tsd, cfg, torch.cat([tc, torch.from_numpy(noise[0])], dim=1),
+                                     torch.full((B, 1), nl_mid, dtype=torch.float32)).numpy()
     base = {
         "value": B / (T * dt / K), "unit": "img/s", "cores": int(threads), "kind": "port-aten",
         "host_cpus": os.cpu_count(), "thread_trials_s_per_step": {str(k): round(v, 3) for k, v in trial.items()},
@@ -126,7 +132,7 @@ def cpu_baseline(cfg, sd, sched_opt, args, synth):
                        "0.25 s per image-step at 128x128 => ~0.004 img/s at T=1000 (BASELINE.md section 2); "
                        "the reference itself cannot run on the GPU box"),
     }
-    return base, {"cond": cond, "noise": noise, "want": x.numpy(), "K": K}
+    return base, {"cond": cond, "noise": noise, "want": x.numpy(), "K": K, "eps_want": eps_want, "nl_mid": nl_mid}
 
 
 def gpu_parity(eng, torch, sample, args, precision, batch):
@@ -152,12 +158,21 @@ def gpu_parity(eng, torch, sample, args, precision, batch):
     eng.sample_end(out.data_ptr())
     eng.synchronize()
     got = out.cpu().numpy().reshape(rep, b, 3, r, r)
+    # the denoiser's output itself (one UNet forward at the mid-schedule noise level, same replication)
+    xin = torch.cat([dc, dn[0]], dim=1).contiguous()
+    nl = torch.full((B,), sample["nl_mid"], dtype=torch.float32, device="cuda")
+    eps = torch.empty((B, 3, r, r), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.unet_forward(xin.data_ptr(), nl.data_ptr(), B, r, r, eps.data_ptr())
+    eng.synchronize()
+    eps_err = float(np.abs(eps.cpu().numpy().reshape(rep, b, 3, r, r) - sample["eps_want"][None]).max())
     eng.set_precision(prev)
     err = np.abs(got - want[None]).max(axis=(1, 2, 3, 4))          # per replica
     st = metrics.batch_psnr_stats(got.reshape(B, 3, r, r), np.tile(want, (rep, 1, 1, 1)))
     # psnr_db: mean over the images that differ after uint8 rounding (null if none differs — JSON has
     # no Infinity); identical_after_rounding counts the images whose PSNR is infinite
     return {"max_abs": float(err.max()), "max_abs_best_replica": float(err.min()), "batch": B, "replicas": rep,
+            "unet_forward_max_abs": eps_err, "unet_forward_rms": float(np.sqrt(np.mean(sample["eps_want"] ** 2))),
             "psnr_db": st["mean_db"], "identical_after_rounding": st["identical"], "images": st["n"], "steps": K,
             "tolerance": 1e-3, "vs": "oracle/sr3_oracle_aten.py on the cpu_baseline sample",
             "fallback_calls": eng.fallback_calls() - fb0}

@@ -99,17 +99,18 @@ def net128():
 
 
 def test_batch_of_300_is_chunked_and_chunking_is_invisible(net128):
-    """B = 300 at 128x128 makes 4.7 GiB activation tensors: one sr3_sample call refuses it (sr3_max_batch ~ 250), the
-    facade runs two equal chunks of 150. Rows must equal the same images sampled ALONE (image_offset = row) and the result
-    must not depend on the number of chunks (f16x3: its products are batch independent up to fp32 summation order)."""
+    """B = 400 at 128x128 makes 4.8 GiB activation tensors (192 channels x 130 x 130 x 400): one sr3_sample call refuses it
+    (sr3_max_batch = 330 for the yml UNet), the facade runs two equal chunks of 200. Rows must equal the same images sampled
+    ALONE (image_offset = row) and the result must not depend on the number of chunks (f16x3: its products are batch
+    independent up to fp32 summation order)."""
     import torch
     netG = net128
     netG.denoise_fn.precision = "f16x3"
     eng = netG.denoise_fn.engine()
     limit = eng.max_batch(128, 128)
-    assert 200 <= limit < 300, limit
-    B, seed = 300, 4711
-    assert netG.chunk_plan(B, limit) == (2, 150)
+    assert 250 <= limit < 400, limit
+    B, seed = 400, 4711
+    assert netG.chunk_plan(B, limit) == (2, 200)
     # the library itself refuses the whole batch, naming the limit
     with pytest.raises(pkg("_lib").Sr3Error, match="at most"):
         big = torch.zeros((B, 3, 128, 128), device="cuda")
@@ -117,15 +118,15 @@ def test_batch_of_300_is_chunked_and_chunking_is_invisible(net128):
         eng.sample(big.data_ptr(), B, 128, 128, out.data_ptr(), None, seed, 0, None)
     cond = torch.from_numpy(synth.synth_cond(B, 128, 16, 31)).cuda()
     two = netG.super_resolution_batch(cond, seed=seed)
-    three = netG.super_resolution_batch(cond, seed=seed, max_chunk=100)          # 3 chunks of 100
-    ragged = netG.super_resolution_batch(cond[:295], seed=seed, max_chunk=100)   # 3 chunks of 99, the last one padded (98 + 1)
+    three = netG.super_resolution_batch(cond, seed=seed, max_chunk=100)          # 4 chunks of 100
+    ragged = netG.super_resolution_batch(cond[:295], seed=seed, max_chunk=100)   # 3 chunks of 99, the last one padded (97 + 2)
     assert two.shape == (B, 3, 128, 128) and torch.isfinite(two).all() and float(two.std()) > 0.2
     d23 = float((two - three).abs().max())
     d2r = float((two[:295] - ragged).abs().max())
-    rows = [0, 149, 150, 299]
+    rows = [0, 199, 200, 399]
     alone = torch.cat([netG.super_resolution_batch(cond[i:i + 1], seed=seed, image_offset=i) for i in rows])
     d_alone = float((two[rows] - alone).abs().max())
-    print(f"B=300 chunked: 2 vs 3 chunks {d23:.2e}; vs ragged 295 {d2r:.2e}; rows sampled alone {d_alone:.2e}")
+    print(f"B=400 chunked: 2 vs 4 chunks {d23:.2e}; vs ragged 295 {d2r:.2e}; rows sampled alone {d_alone:.2e}")
     assert d23 <= 2e-6 and d2r <= 2e-6
     assert d_alone <= 2e-5
     # continous=True through the chunks: ret_img layout of the reference (x_in first, then every frame of the whole batch)
@@ -137,20 +138,21 @@ def test_batch_of_300_is_chunked_and_chunking_is_invisible(net128):
 
 def test_validation_of_15_samples_times_n_images_is_one_call(net128):
     """lib/trainer_temp.py:441-446 runs `cfg.sample` = 15 chains per validation image one at a time; validate_batch stacks
-    them (sample k of image i = row k * N + i). 15 x 17 = 255 rows exceeds one library call: chunked transparently; the
+    them (sample k of image i = row k * N + i). 15 x 23 = 345 rows exceeds one library call (330): chunked transparently; the
     row / seed mapping is what a single-image call with image_offset = row produces."""
     import torch
     validation = pkg("validation")
     netG = net128
     netG.denoise_fn.precision = "f16x3"
-    N, S, seed = 17, 15, 99
+    N, S, seed = 23, 15, 99
     sr = torch.from_numpy(synth.synth_cond(N, 128, 16, 5)).cuda()
     hr = torch.from_numpy(synth.synth_cond(N, 128, 64, 6)).cuda()
     res = validation.validate_batch(netG, sr, hr, samples=S, seed=seed)
     assert res["psnr"].shape == (S, N) and res["ssim"].shape == (S, N) and np.isfinite(res["mean_ssim"])
     imgs = res["images"]
     assert imgs.shape[0] == S * N
-    for k, i in ((0, 0), (7, 3), (14, 16)):
+    assert netG.chunk_plan(S * N, netG.denoise_fn.engine().max_batch(128, 128))[0] == 2
+    for k, i in ((0, 0), (7, 3), (14, 22)):
         row = k * N + i
         alone = netG.super_resolution_batch(sr[i:i + 1], seed=seed, image_offset=row)
         assert float((imgs[row:row + 1] - alone).abs().max()) <= 2e-5
@@ -390,3 +392,32 @@ def test_two_ranks_of_32_images_fp8_path_on():
         print(f"rank {rank}: 2 x 32 (f16f8) vs one process of 64 (f16f8) {d_single:.2e} (all frames {d_frames:.2e}); vs exact f32 {d_exact:.2e}")
         assert d_single <= 1e-4 and d_frames <= 1e-4 and d_exact <= 1e-4
     np.testing.assert_array_equal(res[0][1], res[1][1])                    # both ranks hold the same gathered ret_img
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# weights-stationary kernel of the 64 -> 64 channel convs at the full-resolution level (kernels_conv_ws.hip)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(16, 128, 128), (64, 128, 128), (64, 64, 64), (22, 96, 128)])
+def test_conv_ws_64_to_64_vs_oracle(case):
+    """3x3 / stride 1 / 64 -> 64 channels over >= 2048 tiles of 128 pixels: one persistent block per CU keeps the whole
+    weight tensor in LDS, the waves load their A fragments straight from the tensor (unet.py:80-91 `Block` conv). With bias
+    and the per-image FeatureWiseAffine bias (unet.py:34-50), GroupNorm + Swish in front as the engine runs it; f16x3 bar as
+    for every split-f16 conv: 2e-5 on O(1) outputs. (22 images of 96 x 128: 2112 tiles for 2048 waves — most waves get one tile, some two, some none; 64 x 64: a tile is two image rows.)"""
+    B, H, W = case
+    e = pkg("engine").Engine(synth.tiny_unet_config(), 0)
+    e.load_state_dict(synth.synth_state_dict(e.cfg, 11))
+    e.set_precision("f16x3")
+    rs = np.random.RandomState(B + H)
+    x = rs.standard_normal((B, H, W, 64)).astype(np.float32)
+    w = (rs.standard_normal((64, 64, 3, 3)) / np.sqrt(9 * 64)).astype(np.float32)
+    bias = rs.standard_normal(64).astype(np.float32)
+    cb = rs.standard_normal((B, 64)).astype(np.float32)
+    sc = (1.0 + 0.1 * rs.standard_normal((B, 64))).astype(np.float32)
+    sh = (0.1 * rs.standard_normal((B, 64))).astype(np.float32)
+    got = e.op_conv2d(x, w, bias, gn_scale=sc, gn_shift=sh, swish=True, chan_bias=cb)
+    act = oracle.swish(x * sc[:, None, None, :] + sh[:, None, None, :])
+    want = oracle.conv2d(act, w, bias) + cb[:, None, None, :]
+    err = np.abs(got - want).max()
+    print(f"conv_ws B={B} {H}x{W}: max abs err {err:.2e}")
+    assert err < 2e-5
+    e.close()
