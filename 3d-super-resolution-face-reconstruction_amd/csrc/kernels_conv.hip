@@ -2538,6 +2538,14 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
         p.w_shift = lg(p.Wout);
     }
     if (p.part == nullptr) p.splits = 1;
+    if (p.in_fm) {
+        // the caller wrote this conv's input fragment-major (it asked conv_ws_shape_ok): 64 -> 64 channels over many
+        // 128-pixel tiles — the weights-stationary persistent kernel, and no other kernel can read that layout
+        p.splits = 1;
+        if (conv_ws_supported(p)) launch_conv_ws(p, s);
+        else g_conv_error = "internal: fragment-major input handed to a conv the weights-stationary kernel does not support";
+        return;
+    }
     if (p.prec == 1 && p.ks == 3 && p.stride == 1 && !p.up2 && p.phases == 1 && p.part != nullptr && p.tile_cnt != nullptr &&
         p.in0.pad == 1 && p.in0.W == p.Wout && p.in0.H == p.Hout && p.gnf_gamma == nullptr && !p.no_halo_split) {
         const int hs = conv_halo_splits(M, p.Hout, p.Wout, p.out.C, p.in0.C + (p.in1.p ? p.in1.C : 0));
@@ -2587,10 +2595,6 @@ void launch_conv(const ConvParams &p_in, hipStream_t s) {
     switch (conv_tile_choice(M, p.out.C)) {
     case 0: launch_cfg<128, 32, 4, 1>(p, s); break;
     case 1:
-        // 64 -> 64 channels over many 128-pixel tiles (the full-resolution level): weights-stationary persistent kernel
-        if (p.stats == nullptr || p.stats_slices == (p.Hout * p.Wout) / 128) {
-            if (!halo_off() && conv_ws_supported(p)) { launch_conv_ws(p, s); break; }
-        }
         if (halo_ok(p, 128, 32, 64)) {
 #ifdef SR3_EXPERIMENTS
             if (halo_mfma16() && halo_persistent() && p.ks == 3) launch_halo_pt<128, 64, 32, 3>(p, s);

@@ -1,3 +1,8 @@
+// EXPERIMENT (libsr3hip_exp.so only, SR3_WS=1; profiles/README.md finding 66): built, correct on whole-image-aligned tile
+// ranges, measured SLOWER than the x-halo kernel it was meant to replace (0.31 vs 0.26 ms per 128x128 64 -> 64 conv at B = 64,
+// plus 0.05 ms on the GroupNorm apply pass that has to write the fragment-major layout). The product library compiles none
+// of it. Kept as the measured record of the "persistent block per CU" form VERDICT r3 asked for, with its in-kernel timeline.
+//
 // Weights-stationary 3x3 conv for the 64 -> 64 channel layers of the full-resolution level (split-f16 arithmetic).
 //
 // Replaces, for the seven 128x128-pixel Cin = Cout = 64 convs of a p_sample step (reference unet.py:80-110: block1 / block2
@@ -12,9 +17,12 @@
 //   * ONE persistent block per CU keeps the WHOLE weight tensor in LDS (18 K-steps x 64 rows x 128 B = 144 KB of the
 //     160 KB) for the lifetime of the launch;
 //   * the A operand never touches LDS: the 16x16x32 MFMA's A fragment of a lane is 16 contiguous bytes of one pixel's
-//     32-channel chunk (hi halfs) + 16 more (lo halfs), so every wave loads its fragments straight from the zero-bordered
-//     NHWC tensor into registers (buffer_load_dwordx4, voffset constant per 32-pixel sub-tile, tap / chunk as scalar and
-//     immediate offsets — no vector address arithmetic in the K loop), DEPTH K-steps ahead of their use;
+//     32-channel chunk (hi halfs) + 16 more (lo halfs), so every wave loads its fragments straight from memory into
+//     registers, DEPTH K-steps ahead of their use. The activated input is stored FRAGMENT-MAJOR for that (sr3_internal.h
+//     fm_*; written by the GroupNorm apply pass, split = 3): a fragment is 1 KB of consecutive memory, the wave's
+//     buffer_load_dwordx4 lane-linear — read pixel-major (64 B per pixel, pixels 256 B apart) the texture path took 2.4x as
+//     long and was the bound. Three per-lane offsets (one per dx) serve the whole launch; sub-tile, row and row tile are
+//     scalar offsets, chunk and hi / lo immediates: no vector address arithmetic in the K loop;
 //   * a wave owns its 32 pixels x 64 channels completely: NO barrier and no shared pipeline state inside the launch (one
 //     barrier after the weight load) — eight independent wave pipelines per CU, two per SIMD, which de-phase by
 //     themselves: one wave's epilogue (VALU + stores) runs under the other's MFMAs;
@@ -25,7 +33,18 @@
 // those of the x-halo kernel's 16x16x32 consumers, so results agree with it to fp32 summation order.
 #include "sr3_internal.h"
 
+#ifndef SR3_EXPERIMENTS
+namespace sr3 {
+// product build: the kernel does not exist; no conv input is ever written fragment-major
+bool conv_ws_shape_ok(int, int, int, int, int) { return false; }
+bool conv_ws_supported(const ConvParams &) { return false; }
+void launch_conv_ws(const ConvParams &, hipStream_t) {}
+}  // namespace sr3
+#else
+
+#include <stdio.h>
 #include <type_traits>
+#include <vector>
 
 namespace sr3 {
 
@@ -55,7 +74,19 @@ __device__ __forceinline__ h16x8 ws_load16(const __amdgpu_buffer_rsrc_t rsrc, un
 
 struct WsFrag { h16x8 ah[2], al[2]; };
 
-// One persistent block per CU, 8 waves. Tiles of 128 consecutive output pixels (whole tiles per image, W % 32 == 0).
+// In-kernel timeline (experiments build, ConvParams::dbg bit 6; the buffer rides in ConvParams::part): per wave the shader
+// cycles spent in the K loops (halo + fused 1x1 K-steps), in the epilogues (incl. the issue of the next sub-tile's first
+// loads) and in total, plus the sub-tile count — tools/conv_bench.py prints the averages
+#ifdef SR3_EXPERIMENTS
+#define WS_STAMP(v) if (p.dbg & 64) { v = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#define WS_TL_ADD if (p.dbg & 64) { tl_k += tl_b - tl_a; tl_e += tl_c - tl_b; ++tl_n; }
+#else
+#define WS_STAMP(v)
+#define WS_TL_ADD
+#endif
+
+// One persistent block per CU, 8 waves. Tiles of 128 consecutive output pixels (whole tiles per image; W is 32, 64 or 128,
+// so a tile is 4, 2 or 1 whole image rows and a 32-pixel sub-tile never leaves its row).
 // Wave g (XCD-major numbering, so that the tiles of an image stay in one XCD's L2) takes tiles [g * tpw, (g + 1) * tpw).
 __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p, const int tiles_total, const int tpw) {
     extern __shared__ __attribute__((aligned(128))) float wlds[];
@@ -65,18 +96,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     const int l16 = lane & 15, q = lane >> 4;
 
     // ---- weights -> LDS, once: row R = kstep * 64 + cout (128 B = 32 hi halfs | 32 lo halfs of one 32-channel chunk),
-    //      16-byte slot s of a row holds source chunk s ^ ((cout >> 1) & 7) (conflict-free ds_read_b128 of the fragments)
+    //      16-byte slot s of a row holds source chunk s ^ ((cout >> 1) & 7) (conflict-free ds_read_b128 of the fragments).
+    //      All 18 loads of a thread are in flight before the first LDS write (one round trip, L2-resident after the first block).
     {
         const char *wsrc = reinterpret_cast<const char *>(p.w);
-#pragma unroll 2
+        u32x4 wv[WS_LDS_BYTES / (512 * 16)];
+#pragma unroll
         for (int i = 0; i < WS_LDS_BYTES / (512 * 16); ++i) {
             const int L = i * 512 + tid;
             const int R = L >> 3, s = L & 7;
             const int ks = R >> 6, o = R & 63;
             const int chunk = ks / 9, tap = ks - chunk * 9;      // K-step order of the consumers: chunk-major, then the tap
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(wsrc + ((size_t)(tap * WS_C + o) * WS_C + chunk * 32) * 4 +
-                                                            ((s ^ ((o >> 1) & 7)) << 4));
-            *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(wlds) + R * 128 + s * 16) = v;
+            wv[i] = *reinterpret_cast<const u32x4 *>(wsrc + ((size_t)(tap * WS_C + o) * WS_C + chunk * 32) * 4 + ((s ^ ((o >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < WS_LDS_BYTES / (512 * 16); ++i) {
+            const int L = i * 512 + tid;
+            *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(wlds) + (L >> 3) * 128 + (L & 7) * 16) = wv[i];
         }
     }
     __syncthreads();            // the only barrier of the launch
@@ -91,12 +127,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     if (tile >= tile_end) return;
 
     const int W = p.Wout, HWo = p.Hout * W;
-    const int Hp = p.in0.Hp(), Wp = p.in0.Wp();
+    const int Hp = p.in0.Hp();
+    const int G = fm_groups(W);
+    const unsigned rowb = (unsigned)G * 4096u;                  // bytes of one padded row of the FM tensor (64 channels)
     const int C2a = p.in2.p ? p.in2.C : 0, C2 = C2a + (p.in2b.p ? p.in2b.C : 0);
     const int n2 = C2 >> 5;                                     // fused 1x1 K-steps
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in0.p), 0, -1, 0x00020000);
-    // row offsets of the three dy taps (scalar): padded coordinates of input pixel (y - 1 + dy, x - 1 + dx) are (y + dy, x + dx)
-    const unsigned s_dy[3] = {0u, (unsigned)Wp * 256u, (unsigned)Wp * 512u};
+
+    // A fragment addresses (fragment-major layout, sr3_internal.h): lane (l16, q) of tap dx reads padded pixel
+    // x0 + dx + 16 mt + l16, i.e. slot (l16 + dx) & 15 of group x0 / 16 + mt + ((l16 + dx) >> 4). Per lane THREE constants for
+    // the whole launch; the sub-tile, the row (dy) and the row tile (mt) are scalar offsets, chunk and hi / lo immediates.
+    unsigned v_dx[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+        v_dx[dx] = (unsigned)((l16 + dx) >> 4) * 4096u + (unsigned)q * 256u + (unsigned)((l16 + dx) & 15) * 16u;
+    // byte offset of the group that holds padded pixel (n, y, x0) — uniform
+    auto sub_base = [&](int m) -> unsigned {
+        const int n = p.hw_shift >= 0 ? (m >> p.hw_shift) : m / HWo;
+        const int rem = m - n * HWo;
+        const int y = p.w_shift >= 0 ? (rem >> p.w_shift) : rem / W;
+        return (unsigned)((n * Hp + y) * G + ((rem - y * W) >> 4)) * 4096u;
+    };
 
     // B fragment addresses in LDS: lane (l16, q) reads row (nt * 16 + l16) of the K-step's 64, hi slot q ^ sw, lo slot (4 + q) ^ sw
     const unsigned sw = (unsigned)(l16 >> 1) & 7u;
@@ -107,39 +158,79 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     unsigned range_bits = 0;
     const unsigned psel = split_pair_selector(l16 & 1);
 
-    // sub-tile cursor: sub-tile s (0..3) of tile t covers output pixels m = t * 128 + s * 32 + [0, 32)
-    auto voff_of = [&](int m) -> unsigned {         // per-lane byte offset of (row l16 of row tile 0, tap (0, 0), chunk q)
-        const int n = p.hw_shift >= 0 ? (m >> p.hw_shift) : m / HWo;
-        const int rem = m - n * HWo;
-        const int y = p.w_shift >= 0 ? (rem >> p.w_shift) : rem / W;
-        const int x0 = rem - y * W;
-        return (unsigned)((n * Hp + y) * Wp + x0 + l16) * 256u + (unsigned)q * 16u;
+    // "Touch" loads: whole padded rows of the FM tensor are contiguous (G x 4 KB), so a row a later tile will read is
+    // brought into L2 / L1 by ceil(rowb / 8 KB) one-dword-per-lane loads (lanes 128 B apart), a whole tile ahead of its
+    // first use — the K loop's own fragment loads run only 6 K-steps (~2 us) ahead, which does not cover a first touch of
+    // HBM under load with two waves per SIMD. Written as asm so that no wait is ever generated for the value; the
+    // destination registers stay allocated until the end of the tile (a counted vmcnt wait for any younger fragment load
+    // has covered every older load long before).
+    const int rpt = 128 / W;                                    // image rows per tile
+    const int ipr = (int)((rowb + 8191u) >> 13);                // touch instructions per row (<= 5)
+    const char *a0 = reinterpret_cast<const char *>(p.in0.p);
+    unsigned tch[15] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    // touch rows [row0, row0 + nrows) (padded row indices of image n); at most 15 instructions
+    auto touch_rows = [&](int n, int row0, int nrows) {
+        const unsigned base = (unsigned)((n * Hp + row0) * G) * 4096u;
+        const int cnt = nrows * ipr;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            if (i < cnt) {
+                const int r = i / ipr, k = i - r * ipr;
+                const char *bp = a0 + (size_t)(base + (unsigned)r * rowb + (unsigned)k * 8192u);
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(tch[i]) : "v"((unsigned)lane * 128u), "s"(bp));
+            }
+        }
     };
 
     WsFrag ring[WS_DEPTH];
-    // issue the A fragment loads of halo K-step ks (static) for the sub-tile whose lane offset is vo
-    auto issue = [&](auto ksc, unsigned vo) {
+    // issue the A fragment loads of halo K-step ks (static) for the sub-tile whose group offset is sb
+    auto issue = [&](auto ksc, unsigned sb) {
         constexpr int ks = decltype(ksc)::value;
         // K-step order of the x-halo kernel: chunk-major, then dy, then dx
         constexpr int chunk = ks / 9, tap = ks % 9, dy = tap / 3, dx = tap % 3;
-        constexpr unsigned imm = dx * 256u + chunk * 128u;
+        constexpr unsigned imm = chunk * 2048u;
         WsFrag &f = ring[ks % WS_DEPTH];
+        const unsigned so = sb + (unsigned)dy * rowb;
         // (fenced: left alone the scheduler reverses the order of a group of K-steps' loads, and the first K-step then
         // waits for the last load — vmcnt(0) — instead of for its own four)
         __builtin_amdgcn_sched_barrier(0);
-        f.ah[0] = ws_load16(rs_a, vo + imm, s_dy[dy]);
-        f.al[0] = ws_load16(rs_a, vo + imm + 64u, s_dy[dy]);
-        f.ah[1] = ws_load16(rs_a, vo + imm + 4096u, s_dy[dy]);
-        f.al[1] = ws_load16(rs_a, vo + imm + 4096u + 64u, s_dy[dy]);
+        f.ah[0] = ws_load16(rs_a, v_dx[dx] + imm, so);
+        f.al[0] = ws_load16(rs_a, v_dx[dx] + imm + 1024u, so);
+        f.ah[1] = ws_load16(rs_a, v_dx[dx] + imm, so + 4096u);
+        f.al[1] = ws_load16(rs_a, v_dx[dx] + imm + 1024u, so + 4096u);
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    unsigned vo_cur = voff_of(tile * 128);
-    ws_static_for<WS_DEPTH>([&](auto kc) { issue(kc, vo_cur); });
+#ifdef SR3_EXPERIMENTS
+    long long tl_a = 0, tl_b = 0, tl_c = 0, tl_k = 0, tl_e = 0, tl_n = 0;
+    const long long tl_0 = (long long)__builtin_amdgcn_s_memtime();
+    const long long tr_0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    unsigned sb_cur = sub_base(tile * 128);
+    ws_static_for<WS_DEPTH>([&](auto kc) { issue(kc, sb_cur); });
+    {   // the first tile's rows (behind its first fragments, which the first K-step waits for)
+        const int m0 = tile * 128;
+        const int n = p.hw_shift >= 0 ? (m0 >> p.hw_shift) : m0 / HWo;
+        const int rem = m0 - n * HWo;
+        touch_rows(n, p.w_shift >= 0 ? (rem >> p.w_shift) : rem / W, min(rpt + 2, 15 / ipr));
+    }
+    // The two waves of a SIMD (w and w + 4) would run in lock-step — both in their K loops (sharing the matrix pipe), then
+    // both in their epilogues (pipe idle). Half a K loop of delay for the upper four lets one wave's epilogue run under
+    // the other's MFMAs.
+    if (wid >= 4) __builtin_amdgcn_s_sleep(56);
 
     for (; tile < tile_end; ++tile) {
         const int m_tile = tile * 128;
         const int img = p.hw_shift >= 0 ? (m_tile >> p.hw_shift) : m_tile / HWo;
+        // the rows the NEXT tile adds below this one's (its first rows too if it starts a new image)
+        if (tile + 1 < tile_end) {
+            const int m1 = m_tile + 128;
+            const int n1 = p.hw_shift >= 0 ? (m1 >> p.hw_shift) : m1 / HWo;
+            const int rem1 = m1 - n1 * HWo;
+            const int y1 = p.w_shift >= 0 ? (rem1 >> p.w_shift) : rem1 / W;
+            if (n1 == img) touch_rows(n1, y1 + 2, rpt);
+            else touch_rows(n1, y1, min(rpt + 2, 15 / ipr));
+        }
         // column bias of the tile: conv bias + FeatureWiseAffine bias of the tile's image (a tile never spans two images)
         float cb[4];
 #pragma unroll
@@ -152,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         for (int sub = 0; sub < 4; ++sub) {
             const int m_sub = m_tile + sub * 32;
             const bool last_sub = sub == 3 && tile + 1 >= tile_end;
-            const unsigned vo_next = last_sub ? vo_cur : voff_of(m_sub + 32);      // (tiles of a wave are consecutive)
+            const unsigned sb_next = last_sub ? sb_cur : sub_base(m_sub + 32);      // (tiles of a wave are consecutive)
             f32x4 acc[2][4];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -160,6 +251,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
+            WS_STAMP(tl_a)
             // ---------------- halo K-steps: weights from LDS, A fragments from the register ring
             ws_static_for<WS_KSTEPS>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
@@ -172,18 +264,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                     bql[nt] = *(lds_frag)(bl + nt * 2048);
                 }
                 const WsFrag &f = ring[ks % WS_DEPTH];
+                // term-major: the three products of one accumulator (al*bh, ah*bl, ah*bh — the x-halo kernel's order) are
+                // eight MFMAs apart, so no MFMA waits for the result of the one in front of it
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < 2; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[mt], bql[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
-                    }
                 // the MFMAs have read the ring slot: refill it with K-step ks + DEPTH of this sub-tile (the loads are
                 // issued while the matrix pipe works through the 24 MFMAs above)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ks + WS_DEPTH < WS_KSTEPS) issue(std::integral_constant<int, ks + WS_DEPTH>{}, vo_cur);
+                if constexpr (ks + WS_DEPTH < WS_KSTEPS) issue(std::integral_constant<int, ks + WS_DEPTH>{}, sb_cur);
                 __builtin_amdgcn_sched_barrier(0);
             });
             // ---------------- fused 1x1 K-steps (res_conv over x || skip, or the identity skip as 2^k I): both operands
@@ -225,9 +326,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                         }
                 }
             }
+            WS_STAMP(tl_b)
             // ---------------- the next sub-tile's first fragments go out BEFORE the epilogue and fly under it
             if (!last_sub) {
-                ws_static_for<WS_DEPTH>([&](auto kc) { issue(kc, vo_next); });
+                ws_static_for<WS_DEPTH>([&](auto kc) { issue(kc, sb_next); });
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---------------- epilogue: C/D map col = l16 (+ 16 nt), row = 4 q + r (+ 16 mt)
@@ -275,8 +377,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                     }
                 }
             }
-            vo_cur = vo_next;
+            sb_cur = sb_next;
+            WS_STAMP(tl_c)
+            WS_TL_ADD
         }
+        // (the touch loads of this tile were issued ~30 us ago and are older than every fragment load waited for since)
+#pragma unroll
+        for (int i = 0; i < 15; ++i) asm volatile("" ::"v"(tch[i]));
         // ---- statistics slice of the tile: add the four row groups (lanes q) in a fixed order, lanes q == 0 write
         if (p.stats != nullptr) {
             const int slice = p.stats_slice0 + (m_tile - img * HWo) / 128;
@@ -291,26 +398,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         }
     }
     if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
+#ifdef SR3_EXPERIMENTS
+    if ((p.dbg & 64) && p.part != nullptr && lane == 0) {
+        long long *o = reinterpret_cast<long long *>(p.part) + (size_t)g * 4;
+        o[0] = tl_k; o[1] = tl_e; o[2] = (long long)__builtin_amdgcn_s_memtime() - tl_0;
+        o[3] = tl_n | (((long long)__builtin_amdgcn_s_memrealtime() - tr_0) << 16);      // [15:0] sub-tiles, [63:16] 100 MHz ticks
+    }
+#endif
 }
 
 }  // namespace
 
-// Shapes the weights-stationary kernel takes (launch_conv asks; everything else stays on the LDS-ring kernels)
+// Shapes the weights-stationary kernel takes: the engine asks first (conv_ws_shape_ok) and writes the conv's input
+// fragment-major; launch_conv then checks the launch itself (conv_ws_supported)
+bool conv_ws_shape_ok(int B, int H, int W, int Cin, int Cout) {
+    static const int on = exp_int("SR3_WS", 0);
+    if (!on || env_int("SR3_NO_HALO", 0) || Cin != WS_C || Cout != WS_C) return false;
+    if (!(W == 32 || W == 64 || W == 128) || ((H * W) % 128) != 0) return false;
+    // at least one 128-pixel tile for every wave of a chip-wide launch (each block loads the 144 KB weight tensor once)
+    return (long)B * H * W / 128 >= 2048 && fm_floats(B, WS_C, H, W) * sizeof(float) < (1ull << 32);
+}
+
 bool conv_ws_supported(const ConvParams &p) {
-    static const int off = exp_int("SR3_NO_WS", 0);
-    if (off || p.prec != 1 || p.f8 || p.ks != 3 || p.stride != 1 || p.up2 || p.phases != 1 || p.splits > 1) return false;
-    if (p.gnf_gamma != nullptr || p.resid.p != nullptr || p.dbg != 0) return false;
+    if (!p.in_fm || p.prec != 1 || p.f8 || p.ks != 3 || p.stride != 1 || p.up2 || p.phases != 1 || p.splits > 1) return false;
+    if (p.gnf_gamma != nullptr || p.resid.p != nullptr || (p.dbg & ~64) != 0) return false;
     if (p.in0.C != WS_C || p.in1.p != nullptr || p.out.C != WS_C || p.in0.pad != 1) return false;
     if (p.in0.W != p.Wout || p.in0.H != p.Hout || p.out_step != 1 || p.org_x || p.org_y) return false;
     const int W = p.Wout, HWo = p.Hout * W;
-    if ((W % 32) != 0 || (HWo % 128) != 0) return false;
+    if (!conv_ws_shape_ok(p.B, p.Hout, W, p.in0.C, p.out.C)) return false;
     if (p.in2.p && ((p.in2.C % 32) != 0 || p.in2.H != p.Hout || p.in2.W != W)) return false;
     if (p.in2b.p && (!p.in2.p || (p.in2b.C % 32) != 0 || p.in2b.H != p.Hout || p.in2b.W != W)) return false;
     if (p.in2.p && p.w2 == nullptr) return false;
-    if (p.stats != nullptr && p.stats_slices != HWo / 128) return false;
-    // at least one 128-pixel tile for every wave of a chip-wide launch (each block loads the 144 KB weight tensor once)
-    const long tiles = (long)p.B * HWo / 128;
-    return tiles >= 2048;
+    return p.stats == nullptr || p.stats_slices == HWo / 128;
 }
 
 void launch_conv_ws(const ConvParams &p, hipStream_t s) {
@@ -326,7 +445,30 @@ void launch_conv_ws(const ConvParams &p, hipStream_t s) {
     const int tiles = (int)((long)p.B * p.Hout * p.Wout / 128);
     const int waves = cus * WS_WAVES;
     const int tpw = (tiles + waves - 1) / waves;
+#ifdef SR3_EXPERIMENTS
+    if (p.dbg & 64) {       // timeline run: a buffer of its own, synchronous, averages to stderr
+        ConvParams q = p;
+        long long *buf = nullptr;
+        (void)hipMalloc(&buf, (size_t)waves * 4 * sizeof(long long));
+        (void)hipMemset(buf, 0, (size_t)waves * 4 * sizeof(long long));
+        q.part = reinterpret_cast<float *>(buf);
+        hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, q, tiles, tpw);
+        (void)hipStreamSynchronize(s);
+        std::vector<long long> h((size_t)waves * 4);
+        (void)hipMemcpy(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(buf);
+        double k = 0, e = 0, t = 0, n = 0, rt = 0; int cnt = 0;
+        for (int i = 0; i < waves; ++i) if (h[i * 4 + 3] > 0) { k += h[i * 4]; e += h[i * 4 + 1]; t += h[i * 4 + 2]; n += h[i * 4 + 3] & 0xFFFF; rt += (double)(h[i * 4 + 3] >> 16); ++cnt; }
+        static int printed = 0;
+        if (cnt && printed++ < 3)
+            fprintf(stderr, "ws timeline: %d waves, %.1f sub-tiles each; per sub-tile K loop %.0f cycles, epilogue %.0f; per wave total %.0f cycles "
+                    "(K %.1f %%, epilogue %.1f %%, rest = weight load + first loads %.1f %%); %.1f us per wave on the 100 MHz counter => s_memtime ticks at %.0f MHz\n",
+                    cnt, n / cnt, k / n, e / n, t / cnt, 100 * k / t, 100 * e / t, 100 * (t - k - e) / t, rt / cnt / 100.0, t / (rt / 100.0));
+        return;
+    }
+#endif
     hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, p, tiles, tpw);
 }
 
 }  // namespace sr3
+#endif  // SR3_EXPERIMENTS

@@ -302,6 +302,30 @@ __device__ __forceinline__ void store8(float *dst, int c, const float (&f)[8], f
     }
 }
 
+// SPLIT 3: split-f16 halfs in the fragment-major layout (sr3_internal.h fm_*): hi octet at the lane slot of its pixel,
+// lo octet 1 KB behind it
+__device__ __forceinline__ void store8_fm(const TDesc &out, int n, int y, int x, int c, const float (&f)[8], float &absmax) {
+    h16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float g = f[j];
+        absmax = fmaxf(absmax, fabsf(g));
+        hi[j] = (_Float16)g;
+        lo[j] = (_Float16)(g - (float)hi[j]);
+    }
+    const int yp = y + 1, xp = x + 1;
+    const size_t blk = (((size_t)n * (out.H + 2) + yp) * fm_groups(out.W) + (xp >> 4)) * (out.C >> 5) + (c >> 5);
+    char *d = reinterpret_cast<char *>(out.p) + blk * 2048 + ((c & 31) >> 3) * 256 + (xp & 15) * 16;
+    *reinterpret_cast<h16x8 *>(d) = hi;
+    *reinterpret_cast<h16x8 *>(d + 1024) = lo;
+}
+
+template <int SPLIT>
+__device__ __forceinline__ void store_out(const TDesc &out, int n, int y, int x, int C, int c, const float (&f)[8], float &absmax) {
+    if constexpr (SPLIT == 3) store8_fm(out, n, y, x, c, f, absmax);
+    else store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
+}
+
 // Where the per-(image, channel) GroupNorm statistics of an apply pass come from: fp64 {sum, sum of
 // squares} partials per (image, slice, channel) of one or two source tensors (the halves of a
 // concatenation; written by conv epilogues or by gn_partial_kernel), folded with gamma / beta.
@@ -451,7 +475,7 @@ __global__ __launch_bounds__(GA_T) void gn_apply_kernel(const TDesc in0, const T
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
             }
-            store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
+            store_out<SPLIT>(out, n, y, x, C, c, f, absmax);
         };
         int pix = pix0 + pl;
         int y = pix / W, x = pix - y * W;
@@ -543,7 +567,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, con
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
         }
-        store8<SPLIT>(out.p + out.pix(n, y, x) * C, c, f, absmax);
+        store_out<SPLIT>(out, n, y, x, C, c, f, absmax);
     }
     if (SPLIT && ovf != nullptr && (absmax > (SPLIT == 2 ? SPLIT_F8_MAX : SPLIT_F16_MAX) || absmax_raw > SPLIT_F16_MAX)) *ovf = 1;
 }
@@ -559,6 +583,11 @@ void launch_gn_apply_rows(const TDesc &in0, const TDesc &in1, int B, const float
         if (nr == 2) hipLaunchKernelGGL((gn_apply_rows_kernel<M, S, 2>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf); \
         else hipLaunchKernelGGL((gn_apply_rows_kernel<M, S, 1>), grid, dim3(256), 0, s, in0, in1, scale, shift, out, raw, in_split, ovf);         \
     }
+#ifdef SR3_EXPERIMENTS      // fragment-major output: the weights-stationary conv experiment only (profiles/README.md finding 66)
+    if (split == 3) {
+        if (mode == 0) SR3_GR(0, 3) else if (mode == 1) SR3_GR(1, 3) else SR3_GR(2, 3)
+    } else
+#endif
     if (split == 2) {
         if (mode == 0) SR3_GR(0, 2) else if (mode == 1) SR3_GR(1, 2) else SR3_GR(2, 2)
     } else if (split) {
@@ -600,6 +629,11 @@ static void launch_gn_apply_impl(const TDesc &in0, const TDesc &in1, int B, cons
         hipLaunchKernelGGL((gn_apply_kernel<M, S>), grid, dim3(GA_T), lds, s, in0, in1, scale, shift, st, out, raw, \
                            in_split, ovf, ppb);                                                                    \
     }
+#ifdef SR3_EXPERIMENTS
+    if (split == 3) {
+        if (mode == 0) SR3_GA(0, 3) else if (mode == 1) SR3_GA(1, 3) else SR3_GA(2, 3)
+    } else
+#endif
     if (split == 2) {
         if (mode == 0) SR3_GA(0, 2) else if (mode == 1) SR3_GA(1, 2) else SR3_GA(2, 2)
     } else if (split) {

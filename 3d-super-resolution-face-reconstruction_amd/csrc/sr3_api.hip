@@ -92,6 +92,9 @@ struct Module {
     TDesc up_in;            // M_UP / M_DOWN: split-f16 copy of the raw input (prec 1)
     int slices_default = 0; // st_out.slices when the generic conv produces the statistics (conv_in_kernel: HW / 256)
     TDesc raw1;             // has_res: un-normalised x ‖ skip in the conv input format (fused res_conv)
+    // fragment-major copies of act1 / act2 (sr3_internal.h fm_*): the input layout of the weights-stationary kernel, used in
+    // split-f16 mode where conv_ws_shape_ok says this block's 64 -> 64 channel convs run on it (p == null: not for this block)
+    TDesc fm1, fm2;
     // fused GroupNorm statistics written by the conv that produces out / rb_out / h1 (p == null:
     // the tile does not divide the image, fall back to the statistics kernel)
     StatsRef st_out, st_rb, st_h1;
@@ -483,6 +486,9 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
     // dry run over the graph for sizes
     Carver cv;
     ShapePool acts, h1s, raws;
+    std::map<std::pair<int, int>, uint64_t> fm_off;      // one fragment-major buffer per (h, w) level with 64-channel convs
+    std::vector<uint64_t> fm_at(c->mods.size(), 0);
+    std::vector<char> fm_use(c->mods.size(), 0);       // bit 0: conv1, bit 1: conv2 of the block
     const size_t nm = c->mods.size();
     std::vector<uint64_t> out_off(nm), rb_off(nm), a1_off(nm), a2_off(nm), h1_off(nm), raw_off(nm);
     std::vector<uint64_t> so_off(nm), sr_off(nm), sh_off(nm), tw_off(nm);
@@ -510,6 +516,15 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             a2_off[i] = acts.get(cv, B, oc, h, w);
             h1_off[i] = h1s.get(cv, B, oc, h, w);
             if (m.rb.has_res) raw_off[i] = raws.get(cv, B, m.rb.cin, h, w);
+            {
+                const bool ws1 = conv_ws_shape_ok(B, h, w, m.rb.cin, oc), ws2 = conv_ws_shape_ok(B, h, w, oc, oc);
+                if (ws1 || ws2) {
+                    auto key = std::make_pair(h, w);
+                    if (!fm_off.count(key)) fm_off[key] = cv.take(fm_floats(B, 64, h, w));
+                    fm_at[i] = fm_off[key];
+                    fm_use[i] = (char)((ws1 ? 1 : 0) | (ws2 ? 2 : 0));
+                }
+            }
             if (m.rb.attn) {
                 const uint64_t nu = (uint64_t)B * h * w * oc;
                 if (3 * nu > max_qkv) max_qkv = 3 * nu;
@@ -620,6 +635,8 @@ int ensure_workspace(sr3_ctx *c, int B, int H, int W) {
             m.act2 = desc(a2_off[i], m.oc, m.oh, m.ow, 1);
             m.h1 = desc(h1_off[i], m.oc, m.oh, m.ow, 1);
             if (m.rb.has_res) m.raw1 = desc(raw_off[i], m.rb.cin, m.oh, m.ow, 1);
+            m.fm1 = (fm_use[i] & 1) ? desc(fm_at[i], m.rb.cin, m.oh, m.ow, 1) : TDesc();
+            m.fm2 = (fm_use[i] & 2) ? desc(fm_at[i], m.oc, m.oh, m.ow, 1) : TDesc();
         }
     }
     c->x0 = desc(o_x0, c->in_pad, H, W, 1);
@@ -645,8 +662,10 @@ const TDesc kNone{};
 // GroupNorm statistics + apply (+Swish) (+concat) -> activated, zero-bordered conv input
 // f8: the consumer conv takes the F8C operand format (f8_conv() said so)
 void run_gn_act(sr3_ctx *c, const TDesc &a, const TDesc &b, const GNRef &g, int B, int mode, const TDesc &act,
-                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc(), int in_split = 0, bool f8 = false) {
-    const int fmt = c->prec ? (f8 ? 2 : 1) : 0;
+                const StatsRef &sa, const StatsRef &sb, const TDesc &raw = TDesc(), int in_split = 0, bool f8 = false,
+                bool fm = false) {
+    // fm: `act` is a fragment-major buffer (the consumer conv runs on the weights-stationary kernel; split-f16 mode only)
+    const int fmt = c->prec ? (fm ? 3 : (f8 ? 2 : 1)) : 0;
     c->pbegin(F_GN);
     const float *gamma = c->params[g.gamma].dev, *beta = c->params[g.beta].dev;
     // bytes the pass moves (read + write, 4 B per element each way): above ~200 MB the one-item-per-thread
@@ -682,8 +701,9 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
               const TDesc &in2 = TDesc(), const ConvRef *cv2 = nullptr, const float *bias_override = nullptr,
               const StatsRef &stats = StatsRef(), const TDesc &out_split = TDesc(), const TDesc &in2b = TDesc(),
               bool out_f32 = true, bool resid_split = false, const float *w2_raw = nullptr, const GNRef *gnf = nullptr,
-              bool *gnf_done = nullptr, bool f8 = false) {
+              bool *gnf_done = nullptr, bool f8 = false, bool in_fm = false) {
     ConvParams p;
+    p.in_fm = in_fm ? 1 : 0;
     p.in0 = a; p.in1 = b; p.B = B; p.Hout = out.H; p.Wout = out.W;
     p.ks = cv.ks; p.stride = stride; p.up2 = up2;
     p.prec = activated ? c->prec : 0;
@@ -727,7 +747,7 @@ void run_conv(sr3_ctx *c, const TDesc &a, const TDesc &b, const ConvRef &cv, int
         char tag[160];
         snprintf(tag, sizeof tag, "conv k%d s%d u%d %dx%d cin%d(%d+%d) cout%d res%d fused1x1:%d prec%d%s", cv.ks, stride,
                  up2, out.H, out.W, cv.cin, a.C, b.p ? b.C : 0, cv.cout, resid.p ? 1 : 0, cv2 ? cv2->cin : 0, p.prec,
-                 use_gnf ? " +gn" : (p.f8 ? " f8c" : ""));
+                 use_gnf ? " +gn" : (p.f8 ? " f8c" : (p.in_fm ? " ws" : "")));
         c->pend(2.0 * (double)B * out.H * out.W * cv.cout * ((double)(cv.ks * cv.ks) * cv.cin + (cv2 ? cv2->cin : 0)), tag);
     }
 }
@@ -758,27 +778,33 @@ void run_res(sr3_ctx *c, Module &m, const TDesc &x, const StatsRef &sx, const TD
     // (conv2's fused 1x1 K-steps read x / skip — or the raw concatenation — in 32-channel chunks of the plain split format)
     const bool fused_ok = !rb.has_res || (direct ? ((xr.C % 32) == 0 && (!skip.p || (skr.C % 32) == 0)) : (rb.cin % 32) == 0);
     const bool f8a = f8_conv(c, rb.c1, B, h, w), f8b = fused_ok && f8_conv(c, rb.c2, B, h, w);
-    run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, m.act1, sx, ss,
-               rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0), f8a);
+    // 64 -> 64 channel convs of the full-resolution level: weights-stationary kernel on a fragment-major input (the epilogue
+    // residual is the one thing it does not do: such a conv2 stays on the x-halo kernel)
+    const bool wsa = c->prec == 1 && m.fm1.p != nullptr && !skip.p && !f8a;
+    const bool ws2_resid = !rb.has_res && !(rb.ident_w && xr.p && !no_ident);
+    const bool wsb = c->prec == 1 && m.fm2.p != nullptr && !f8b && !ws2_resid;
+    const TDesc &a1 = wsa ? m.fm1 : m.act1, &a2 = wsb ? m.fm2 : m.act2;
+    run_gn_act(c, x_so ? xr : x, (skip.p && sk_so) ? skr : skip, rb.gn1, B, 2, a1, sx, ss,
+               rb.has_res && !direct ? m.raw1 : kNone, (x_so ? 1 : 0) | (skip.p && sk_so ? 2 : 0), f8a, wsa);
     // block1's conv + FeatureWiseAffine bias, then block2's GroupNorm + Swish: inside the conv where the producer-side
     // form applies (h1 then never exists: the conv writes act2), else as the apply pass over the fp32 h1
     bool gn2_done = false;
     const bool want_gnf = c->prec && !c->no_fused_stats;     // (only then may the conv write act2 itself: h1 is never range-checked as a twin otherwise)
-    run_conv(c, m.act1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1,
-             want_gnf ? m.act2 : kNone, kNone, true, false, nullptr, want_gnf ? &rb.gn2 : nullptr, &gn2_done, f8a);
-    if (!gn2_done) run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, m.act2, m.st_h1, StatsRef(), TDesc(), 0, f8b);
+    run_conv(c, a1, kNone, rb.c1, B, 1, 0, c->cbias + rb.nf_off, kNone, m.h1, true, kNone, nullptr, nullptr, m.st_h1,
+             want_gnf ? m.act2 : kNone, kNone, true, false, nullptr, want_gnf ? &rb.gn2 : nullptr, &gn2_done, f8a, wsa);
+    if (!gn2_done) run_gn_act(c, m.h1, kNone, rb.gn2, B, 2, a2, m.st_h1, StatsRef(), TDesc(), 0, f8b, wsb);
     // block2 + skip path in one launch: conv3x3(act2) [+ res_conv 1x1 (raw x ‖ skip) as extra
     // K-steps | + x as residual when the block keeps its width]
     const TDesc tw = rb.attn ? kNone : m.out_s;      // with attention the out-projection writes the module output
     if (rb.has_res)
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, direct ? xr : m.raw1, &rb.res,
-                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone, !out_so, false, nullptr, nullptr, nullptr, f8b);
+        run_conv(c, a2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, direct ? xr : m.raw1, &rb.res,
+                 rb.fused_bias, m.st_rb, tw, direct && skip.p ? skr : kNone, !out_so, false, nullptr, nullptr, nullptr, f8b, wsb);
     else if (c->prec && rb.ident_w && xr.p && !no_ident)
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, xr, nullptr, nullptr, m.st_rb,
-                 tw, kNone, !out_so, false, rb.ident_w, nullptr, nullptr, f8b);
+        run_conv(c, a2, kNone, rb.c2, B, 1, 0, nullptr, kNone, m.rb_out, true, xr, nullptr, nullptr, m.st_rb,
+                 tw, kNone, !out_so, false, rb.ident_w, nullptr, nullptr, f8b, wsb);
     else
-        run_conv(c, m.act2, kNone, rb.c2, B, 1, 0, nullptr, x_so ? xr : x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb,
-                 tw, kNone, !out_so, x_so, nullptr, nullptr, nullptr, f8b);
+        run_conv(c, a2, kNone, rb.c2, B, 1, 0, nullptr, x_so ? xr : x, m.rb_out, true, kNone, nullptr, nullptr, m.st_rb,
+                 tw, kNone, !out_so, x_so, nullptr, nullptr, nullptr, f8b, wsb);
     if (rb.attn) {
         run_gn_act(c, m.rb_out, kNone, rb.agn, B, 1, m.act2, m.st_rb, StatsRef());
         const TDesc qkv = unpadded(c->qkvb, 3 * rb.cout, h, w);
@@ -1711,22 +1737,28 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     }
     // the engine's own sequence: (GroupNorm apply | copy) + concat into a zero-bordered tensor, then conv
     TDesc a; a.C = Cin; a.H = Hin; a.W = Win; a.pad = 1;
-    HIP_OK(hipMalloc(&act, a.floats(B) * sizeof(float)));
-    HIP_OK(hipMemsetAsync(act, 0, a.floats(B) * sizeof(float), c->stream));
+    // 64 -> 64 channels over many tiles: fragment-major input + the weights-stationary kernel, as run_res does it
+    const bool ws = c->prec == 1 && !f8 && ks == 3 && stride == 1 && !up2 && C1 == 0 && !resid_dev &&
+                    conv_ws_shape_ok(B, Hin, Win, Cin, Cout);
+    const size_t act_floats = ws ? std::max(a.floats(B), fm_floats(B, Cin, Hin, Win)) : a.floats(B);
+    HIP_OK(hipMalloc(&act, act_floats * sizeof(float)));
+    HIP_OK(hipMemsetAsync(act, 0, act_floats * sizeof(float), c->stream));
     a.p = act;
     const TDesc i0 = unpadded(const_cast<float *>(in0_dev), C0, Hin, Win);
     const TDesc i1 = in1_dev ? unpadded(const_cast<float *>(in1_dev), C1, Hin, Win) : kNone;
     if (range_reset(c)) return -1;
-    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, f8 ? 2 : c->prec, a, c->stream,
-                    TDesc(), 0, c->d_ovf);
+    launch_gn_apply(i0, i1, B, gn_scale_dev, gn_shift_dev, gn_scale_dev ? (swish ? 2 : 1) : 0, ws ? 3 : (f8 ? 2 : c->prec), a,
+                    c->stream, TDesc(), 0, c->d_ovf);
     const int pad = ks / 2, Hv = Hin << up2, Wv = Win << up2;
     ConvParams p;
     p.in0 = a; p.B = B;
     p.Hout = (Hv + 2 * pad - ks) / stride + 1; p.Wout = (Wv + 2 * pad - ks) / stride + 1;
     p.ks = ks; p.stride = stride; p.up2 = up2;
     p.prec = c->prec; p.w_unscale = w_unscale; p.f8 = f8 ? 1 : 0;
+    p.in_fm = ws ? 1 : 0;
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
     p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
+    p.ovf = c->d_ovf;            // (range bits of twin stores and the 'wait gave up' bit of the in-place split-K)
     if (resid_dev) p.resid = unpadded(const_cast<float *>(resid_dev), Cout, p.Hout, p.Wout);
     // split-K exactly as the engine would choose it for this problem (in place or conv + reduce kernel)
     float *part = nullptr;
@@ -1783,7 +1815,9 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     float *w, *bias, *sc, *sh, *cb;
     HIP_OK(hipMalloc(&i0.p, i0.floats(B) * 4));
     if (C1) HIP_OK(hipMalloc(&i1.p, i1.floats(B) * 4));
-    HIP_OK(hipMalloc(&act.p, act.floats(B) * 4));
+    const bool ws_probe = c->prec == 1 && !(c->f8corr && ks == 3 && stride == 1 && !up2 && conv_f8_supported(B, Hin, Win, Cout, Cin)) &&
+                          ks == 3 && stride == 1 && !up2 && C1 == 0 && !with_resid && conv_ws_shape_ok(B, Hin, Win, Cin, Cout);
+    HIP_OK(hipMalloc(&act.p, std::max(act.floats(B), ws_probe ? fm_floats(B, Cin, Hin, Win) : (size_t)0) * 4));
     HIP_OK(hipMalloc(&out.p, out.floats(B) * 4));
     HIP_OK(hipMalloc(&res.p, res.floats(B) * 4));
     HIP_OK(hipMalloc(&w, n_w * 4));
@@ -1801,9 +1835,11 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     p.prec = c->prec;
     const bool f8 = c->prec == 1 && c->f8corr && ks == 3 && stride == 1 && !up2 && conv_f8_supported(B, Hin, Win, Cout, Cin);
     p.f8 = f8 ? 1 : 0;       // (timing: the operand bytes are random either way)
+    p.in_fm = ws_probe ? 1 : 0;
     p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
     if (with_resid) p.resid = res;
     p.out = out;
+    p.ovf = c->d_ovf;
     // split-K exactly as the engine would choose it for this problem (partials on a scratch buffer)
     float *part = nullptr;
     {
@@ -1823,7 +1859,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     HIP_OK(hipEventRecord(e0, c->stream));
     for (int i = 0; i < iters; ++i) go();
     HIP_OK(hipEventRecord(e1, c->stream));
-    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, f8 ? 2 : c->prec, act, c->stream);
+    for (int i = 0; i < iters; ++i) launch_gn_apply(i0, C1 ? i1 : kNone, B, sc, sh, mode, ws_probe ? 3 : (f8 ? 2 : c->prec), act, c->stream);
     HIP_OK(hipEventRecord(e2, c->stream));
     HIP_OK(hipEventSynchronize(e2));
     float ms = 0.f;

@@ -110,6 +110,9 @@ struct ConvParams {
     // life once one of its bounded inter-block waits gave up (SR3_FLAG_GNF_TIMEOUT): the conv then runs unsplit on the
     // generic 64x64 tile, whose blocks never wait for each other
     int no_halo_split = 0;
+    // 1: in0 is stored FRAGMENT-MAJOR (fm_* below) — the input layout of the weights-stationary kernel
+    // (kernels_conv_ws.hip); launch_conv runs such a conv on that kernel or reports an error, never on another one
+    int in_fm = 0;
     // split-f16 range check: any value stored in the split format (out_split) with |v| > 65504 (or
     // non-finite) sets *ovf = 1; the API call that ran the launch then fails (never a silent clamp)
     int *ovf = nullptr;
@@ -175,8 +178,20 @@ void launch_conv(const ConvParams &p, hipStream_t s);
 // launch_conv never aborts the process: a request it cannot honour (a caller / library bug) launches nothing and leaves
 // a message here; returns it once (nullptr if none) — the C-ABI entry points fail the call with it
 const char *conv_take_error();
-// weights-stationary kernel for the 64 -> 64 channel 3x3 convs of the full-resolution level (kernels_conv_ws.hip):
-// launch_conv takes it where conv_ws_supported says so (p as launch_conv sees it: hw_shift / w_shift set)
+// Weights-stationary kernel for the 64 -> 64 channel 3x3 convs of the full-resolution level (kernels_conv_ws.hip). Its
+// waves load their MFMA A fragments straight from memory, so the activated input is stored FRAGMENT-MAJOR ("FM"): the
+// zero-bordered tensor [B][H + 2][W + 2][C] regrouped per padded row into groups of 16 consecutive pixels, per group and
+// 32-channel chunk one 2 KB block  [hi | lo][q = 0..3][pixel 0..15][16 B]  — the 16 bytes (8 halfs of channel octet q) that
+// lane (pixel, q) of a 16x16x32 MFMA holds, so one fragment of 16 pixels is 1 KB of consecutive memory (a wave's load is
+// lane-linear: perfectly coalesced; the pixel-major layout costs the texture path 2.4x, profiles/README.md finding 66).
+// Rows are padded to whole groups; borders and group padding stay zero like every activation border.
+//   byte offset of (n, padded y, padded x, channel c), hi half of its octet:
+//     ((((n * (H + 2) + yp) * G + (xp >> 4)) * (C / 32) + (c >> 5)) * 2048 + ((c & 31) >> 3) * 256 + (xp & 15) * 16,  lo: + 1024
+__host__ __device__ inline int fm_groups(int W) { return (W + 2 + 15) >> 4; }                      // G: 16-pixel groups per padded row
+inline size_t fm_floats(int B, int C, int H, int W) { return (size_t)B * (H + 2) * fm_groups(W) * (C / 32) * 512; }
+// shape test shared by the engine (which writes the conv's input in FM form) and launch_conv: 3x3 / stride 1 / split-f16
+// conv of this shape runs on the weights-stationary kernel when its input is FM (ConvParams::in_fm)
+bool conv_ws_shape_ok(int B, int H, int W, int Cin, int Cout);
 bool conv_ws_supported(const ConvParams &p);
 void launch_conv_ws(const ConvParams &p, hipStream_t s);
 // Upsample (nearest x2) + conv3x3 (unet.py:58-65) as four sub-pixel phases: output pixels of
@@ -225,7 +240,8 @@ void launch_groupnorm_finalize(const StatsRef &s0, int C0, const StatsRef &s1, i
 // out[n,y,x,:] = act(concat(in0,in1)[n,y,x,:] * scale[n,:] + shift[n,:]); mode 0 copy, 1 affine,
 // 2 affine + Swish. out.C == in0.C + in1.C; writes the interior only. split = 1 stores every
 // 32-channel chunk as 32 hi halfs | 32 lo halfs (the conv's prec 1 input format), split = 2 as
-// 32 hi halfs | 32 x e4m3(lo * 2^SR3_F8_XL) | 32 x e4m3(hi * 2^SR3_F8_XH) (ConvParams::f8; `raw` stays format 1).
+// 32 hi halfs | 32 x e4m3(lo * 2^SR3_F8_XL) | 32 x e4m3(hi * 2^SR3_F8_XH) (ConvParams::f8; `raw` stays format 1),
+// split = 3 as format 1 in the fragment-major layout (fm_*: out.p must hold fm_floats(); ConvParams::in_fm).
 // raw (optional, p != nullptr): additionally stores the un-normalised concatenation in the same
 // format (the input of a fused res_conv).
 // in_split: bit 0 / bit 1 = in0 / in1 is itself stored in the split-f16 format (split-only tensors)

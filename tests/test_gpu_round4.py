@@ -106,7 +106,7 @@ def test_batch_of_300_is_chunked_and_chunking_is_invisible(net128):
     import torch
     netG = net128
     netG.denoise_fn.precision = "f16x3"
-    eng = netG.denoise_fn.engine()
+    eng = netG._engine()                  # (engine with this net's weights and schedule pushed)
     limit = eng.max_batch(128, 128)
     assert 250 <= limit < 400, limit
     B, seed = 400, 4711
@@ -151,7 +151,7 @@ def test_validation_of_15_samples_times_n_images_is_one_call(net128):
     assert res["psnr"].shape == (S, N) and res["ssim"].shape == (S, N) and np.isfinite(res["mean_ssim"])
     imgs = res["images"]
     assert imgs.shape[0] == S * N
-    assert netG.chunk_plan(S * N, netG.denoise_fn.engine().max_batch(128, 128))[0] == 2
+    assert netG.chunk_plan(S * N, netG._engine().max_batch(128, 128))[0] == 2
     for k, i in ((0, 0), (7, 3), (14, 22)):
         row = k * N + i
         alone = netG.super_resolution_batch(sr[i:i + 1], seed=seed, image_offset=row)
@@ -176,7 +176,7 @@ def _filler():
 def test_inplace_splitk_with_cotenant_holding_the_cus():
     """The 8x8-level conv of the B = 64 step (M = 4096, 512 -> 512) runs on 128x128 x-halo tiles with the K range split
     over 4 blocks per tile that WAIT for each other (reduce-scatter tail): 512 blocks for the chip's 512 slots. Here a
-    second stream holds almost every slot for 40 ms (510 holders of 60 KB LDS: two per CU, so no 73 KB conv block fits
+    second stream holds almost every slot for 300 ms (510 holders of 60 KB LDS: two per CU, so no 73 KB conv block fits
     beside them; ~2 conv slots stay free): a block that gets a slot cannot see its siblings arrive, its bounded wait
     (5 ms) gives up, and the library replays the conv on the path without inter-block waits. Asserted: the call returns
     (no hang), the result equals the undisturbed run and the oracle, and the context keeps working afterwards."""
@@ -194,7 +194,7 @@ def test_inplace_splitk_with_cotenant_holding_the_cus():
     want = oracle.conv2d(x, w, bias)               # NHWC in / out
     assert np.abs(calm - want).max() < 2e-5
     fl = _filler()
-    assert fl.filler_launch(510, 60 * 1024, 4_000_000) == 0        # 40 ms
+    assert fl.filler_launch(510, 60 * 1024, 30_000_000) == 0       # 300 ms (op_conv2d packs its weights on the host first)
     t0 = time.time()
     while fl.filler_started() < 500 and time.time() - t0 < 5.0:
         time.sleep(0.0005)
@@ -208,7 +208,7 @@ def test_inplace_splitk_with_cotenant_holding_the_cus():
     replays = e.replay_calls()
     print(f"co-tenant: {started} holders resident; conv returned after {dt * 1e3:.1f} ms; replays {replays}; "
           f"warnings {[type(v.message).__name__ for v in wlist]}")
-    assert dt < 5.0                                      # bounded: 40 ms of holders + a handful of 5 ms waits
+    assert dt < 5.0                                      # bounded: 300 ms of holders (~2 x 60 waits of 5 ms under them) + the replay
     assert np.abs(busy - want).max() < 2e-5
     assert np.abs(busy - calm).max() < 2e-6              # (split vs unsplit K order: fp32 summation order only)
     if replays:
@@ -258,7 +258,7 @@ def test_sampler_replays_the_segment_when_a_wait_gives_up():
     # the context stays on the non-waiting path and keeps working
     again = e.sample_np(cond, seed=21)
     assert e.replay_calls() == 1
-    np.testing.assert_array_equal(again, busy)
+    assert np.abs(again - busy).max() <= 2e-5       # (busy ran its first steps on the split-K path: K summation order)
     e.close()
 
 
@@ -395,14 +395,16 @@ def test_two_ranks_of_32_images_fp8_path_on():
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# weights-stationary kernel of the 64 -> 64 channel convs at the full-resolution level (kernels_conv_ws.hip)
+# the 64 -> 64 channel convs of the full-resolution level
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", [(16, 128, 128), (64, 128, 128), (64, 64, 64), (22, 96, 128)])
-def test_conv_ws_64_to_64_vs_oracle(case):
-    """3x3 / stride 1 / 64 -> 64 channels over >= 2048 tiles of 128 pixels: one persistent block per CU keeps the whole
-    weight tensor in LDS, the waves load their A fragments straight from the tensor (unet.py:80-91 `Block` conv). With bias
-    and the per-image FeatureWiseAffine bias (unet.py:34-50), GroupNorm + Swish in front as the engine runs it; f16x3 bar as
-    for every split-f16 conv: 2e-5 on O(1) outputs. (22 images of 96 x 128: 2112 tiles for 2048 waves — most waves get one tile, some two, some none; 64 x 64: a tile is two image rows.)"""
+def test_conv_64_to_64_full_resolution_vs_oracle(case):
+    """3x3 / stride 1 / 64 -> 64 channels over >= 2048 tiles of 128 pixels (unet.py:80-91 `Block` conv at the 128x128
+    level: 2.1 ms of the B = 64 step, the shapes furthest below the roofline). With bias and the per-image
+    FeatureWiseAffine bias (unet.py:34-50), GroupNorm + Swish in front as the engine runs it; f16x3 bar as for every
+    split-f16 conv: 2e-5 on O(1) outputs. The product library runs them on the x-halo kernel; the experiments build with
+    SR3_WS=1 on the weights-stationary persistent kernel of profiles/README.md finding 66 (kernels_conv_ws.hip) — the same
+    cases are its parity test (SR3_LIB=.../libsr3hip_exp.so SR3_WS=1 pytest -k conv_64_to_64)."""
     B, H, W = case
     e = pkg("engine").Engine(synth.tiny_unet_config(), 0)
     e.load_state_dict(synth.synth_state_dict(e.cfg, 11))
@@ -418,6 +420,6 @@ def test_conv_ws_64_to_64_vs_oracle(case):
     act = oracle.swish(x * sc[:, None, None, :] + sh[:, None, None, :])
     want = oracle.conv2d(act, w, bias) + cb[:, None, None, :]
     err = np.abs(got - want).max()
-    print(f"conv_ws B={B} {H}x{W}: max abs err {err:.2e}")
+    print(f"conv 64->64 B={B} {H}x{W}: max abs err {err:.2e}")
     assert err < 2e-5
     e.close()
