@@ -18,11 +18,13 @@
 //     160 KB) for the lifetime of the launch;
 //   * the A operand never touches LDS: the 16x16x32 MFMA's A fragment of a lane is 16 contiguous bytes of one pixel's
 //     32-channel chunk (hi halfs) + 16 more (lo halfs), so every wave loads its fragments straight from memory into
-//     registers, DEPTH K-steps ahead of their use. The activated input is stored FRAGMENT-MAJOR for that (sr3_internal.h
-//     fm_*; written by the GroupNorm apply pass, split = 3): a fragment is 1 KB of consecutive memory, the wave's
-//     buffer_load_dwordx4 lane-linear — read pixel-major (64 B per pixel, pixels 256 B apart) the texture path took 2.4x as
-//     long and was the bound. Three per-lane offsets (one per dx) serve the whole launch; sub-tile, row and row tile are
-//     scalar offsets, chunk and hi / lo immediates: no vector address arithmetic in the K loop;
+//     registers, two (chunk, dy) groups ahead of their use. The activated input is stored FRAGMENT-MAJOR for that
+//     (sr3_internal.h fm_*; written by the GroupNorm apply pass, split = 3): the fragment of 16 pixels is 1 KB of consecutive
+//     memory and the wave's buffer_load_dwordx4 is lane-linear — read pixel-major (64 B per pixel, pixels 256 B apart) the
+//     texture path took 2.4x as long and was the bound. Only ALIGNED 16-pixel blocks are loaded (three per group and half:
+//     6 KB for three K-steps); the fragments of the taps dx = 1, 2 are made from them by DPP row shifts (a DPP row is the
+//     16 pixels of one channel octet). ONE per-lane offset (lane * 16) serves every A load of the launch; sub-tile, row
+//     and block are scalar offsets, chunk and hi / lo immediates: no vector address arithmetic in the K loop;
 //   * a wave owns its 32 pixels x 64 channels completely: NO barrier and no shared pipeline state inside the launch (one
 //     barrier after the weight load) — eight independent wave pipelines per CU, two per SIMD, which de-phase by
 //     themselves: one wave's epilogue (VALU + stores) runs under the other's MFMAs;
@@ -58,7 +60,8 @@ constexpr int WS_C = 64;                       // Cin == Cout == 64
 constexpr int WS_KSTEPS = 18;                  // 9 taps x 2 chunks of 32 channels
 constexpr int WS_LDS_BYTES = WS_KSTEPS * WS_C * 128;      // 147,456
 constexpr int WS_WAVES = 8;
-constexpr int WS_DEPTH = 6;                    // K-steps of A fragments in flight per wave (16 registers each)
+constexpr int WS_GROUPS = 6;                   // (chunk, dy) groups of a sub-tile: three K-steps (dx) each
+constexpr int WS_RING = 3;                     // groups of A blocks in registers per wave (24 registers each)
 
 template <int N, class F>
 __device__ __forceinline__ void ws_static_for(F &&f) {
@@ -68,22 +71,37 @@ __device__ __forceinline__ void ws_static_for(F &&f) {
     }
 }
 
-__device__ __forceinline__ h16x8 ws_load16(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+__device__ __forceinline__ u32x4 ws_load16(const __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
-struct WsFrag { h16x8 ah[2], al[2]; };
+// The A operand of one (chunk, dy) group: three 16-pixel blocks of the fragment-major tensor (pixels x0 .. x0 + 47 of the
+// padded row; the third only for its first two pixels), hi and lo halfs — each block is 1 KB of consecutive memory and
+// IS the MFMA fragment of its 16 pixels for tap dx = 0 (lane (l16, q) = slot q * 16 + l16 of the block).
+struct WsGroup { u32x4 h[3], l[3]; };
 
-// In-kernel timeline (experiments build, ConvParams::dbg bit 6; the buffer rides in ConvParams::part): per wave the shader
-// cycles spent in the K loops (halo + fused 1x1 K-steps), in the epilogues (incl. the issue of the next sub-tile's first
-// loads) and in total, plus the sub-tile count — tools/conv_bench.py prints the averages
-#ifdef SR3_EXPERIMENTS
+// Fragment of a row tile for tap dx from the aligned blocks: lane l16 needs pixel l16 + dx of block `a`, or pixel
+// l16 + dx - 16 of the next block `nx`. The 16 lanes of one q are one DPP row, so a pixel shift is a row shift: two DPP
+// moves per register (row_shr from the next block into the lanes that the row_shl of this block leaves untouched).
+template <int DX>
+__device__ __forceinline__ h16x8 ws_shift(const u32x4 a, const u32x4 nx) {
+    if constexpr (DX == 0) {
+        return __builtin_bit_cast(h16x8, a);
+    } else {
+        u32x4 r;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int u = __builtin_amdgcn_update_dpp((int)nx[d], (int)nx[d], 0x110 + (16 - DX), 0xF, 0xF, true);   // row_shr:16-DX (other lanes: don't care)
+            r[d] = (unsigned)__builtin_amdgcn_update_dpp(u, (int)a[d], 0x100 + DX, 0xF, 0xF, false);           // row_shl:DX
+        }
+        return __builtin_bit_cast(h16x8, r);
+    }
+}
+
+// In-kernel timeline (ConvParams::dbg bit 6): per wave the shader cycles spent in the K loops (halo + fused 1x1 K-steps), in
+// the epilogues and in total, the sub-tile count and the 100 MHz real-time ticks — launch_conv_ws prints the averages
 #define WS_STAMP(v) if (p.dbg & 64) { v = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 #define WS_TL_ADD if (p.dbg & 64) { tl_k += tl_b - tl_a; tl_e += tl_c - tl_b; ++tl_n; }
-#else
-#define WS_STAMP(v)
-#define WS_TL_ADD
-#endif
 
 // One persistent block per CU, 8 waves. Tiles of 128 consecutive output pixels (whole tiles per image; W is 32, 64 or 128,
 // so a tile is 4, 2 or 1 whole image rows and a 32-pixel sub-tile never leaves its row).
@@ -133,15 +151,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     const int C2a = p.in2.p ? p.in2.C : 0, C2 = C2a + (p.in2b.p ? p.in2b.C : 0);
     const int n2 = C2 >> 5;                                     // fused 1x1 K-steps
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in0.p), 0, -1, 0x00020000);
-
-    // A fragment addresses (fragment-major layout, sr3_internal.h): lane (l16, q) of tap dx reads padded pixel
-    // x0 + dx + 16 mt + l16, i.e. slot (l16 + dx) & 15 of group x0 / 16 + mt + ((l16 + dx) >> 4). Per lane THREE constants for
-    // the whole launch; the sub-tile, the row (dy) and the row tile (mt) are scalar offsets, chunk and hi / lo immediates.
-    unsigned v_dx[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-        v_dx[dx] = (unsigned)((l16 + dx) >> 4) * 4096u + (unsigned)q * 256u + (unsigned)((l16 + dx) & 15) * 16u;
-    // byte offset of the group that holds padded pixel (n, y, x0) — uniform
+    const unsigned v_lane = (unsigned)lane * 16u;               // the ONE per-lane offset of every A load of the launch
+    // byte offset of the 16-pixel block that holds padded pixel (n, y, x0) — uniform
     auto sub_base = [&](int m) -> unsigned {
         const int n = p.hw_shift >= 0 ? (m >> p.hw_shift) : m / HWo;
         const int rem = m - n * HWo;
@@ -158,62 +169,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     unsigned range_bits = 0;
     const unsigned psel = split_pair_selector(l16 & 1);
 
-    // "Touch" loads: whole padded rows of the FM tensor are contiguous (G x 4 KB), so a row a later tile will read is
-    // brought into L2 / L1 by ceil(rowb / 8 KB) one-dword-per-lane loads (lanes 128 B apart), a whole tile ahead of its
-    // first use — the K loop's own fragment loads run only 6 K-steps (~2 us) ahead, which does not cover a first touch of
-    // HBM under load with two waves per SIMD. Written as asm so that no wait is ever generated for the value; the
-    // destination registers stay allocated until the end of the tile (a counted vmcnt wait for any younger fragment load
-    // has covered every older load long before).
-    const int rpt = 128 / W;                                    // image rows per tile
-    const int ipr = (int)((rowb + 8191u) >> 13);                // touch instructions per row (<= 5)
-    const char *a0 = reinterpret_cast<const char *>(p.in0.p);
-    unsigned tch[15] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    // touch rows [row0, row0 + nrows) (padded row indices of image n); at most 15 instructions
-    auto touch_rows = [&](int n, int row0, int nrows) {
-        const unsigned base = (unsigned)((n * Hp + row0) * G) * 4096u;
-        const int cnt = nrows * ipr;
-#pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            if (i < cnt) {
-                const int r = i / ipr, k = i - r * ipr;
-                const char *bp = a0 + (size_t)(base + (unsigned)r * rowb + (unsigned)k * 8192u);
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(tch[i]) : "v"((unsigned)lane * 128u), "s"(bp));
-            }
-        }
-    };
-
-    WsFrag ring[WS_DEPTH];
-    // issue the A fragment loads of halo K-step ks (static) for the sub-tile whose group offset is sb
-    auto issue = [&](auto ksc, unsigned sb) {
-        constexpr int ks = decltype(ksc)::value;
-        // K-step order of the x-halo kernel: chunk-major, then dy, then dx
-        constexpr int chunk = ks / 9, tap = ks % 9, dy = tap / 3, dx = tap % 3;
+    WsGroup ring[WS_RING];
+    // issue the six block loads of group gi (static: chunk-major, then dy — the x-halo kernel's K-step order) of the sub-tile
+    // whose first block is at sb. Every load is lane-linear: voffset = lane * 16, everything else scalar / immediate.
+    auto issue = [&](auto gic, unsigned sb) {
+        constexpr int gi = decltype(gic)::value;
+        constexpr int chunk = gi / 3, dy = gi % 3;
         constexpr unsigned imm = chunk * 2048u;
-        WsFrag &f = ring[ks % WS_DEPTH];
+        WsGroup &f = ring[gi % WS_RING];
         const unsigned so = sb + (unsigned)dy * rowb;
-        // (fenced: left alone the scheduler reverses the order of a group of K-steps' loads, and the first K-step then
-        // waits for the last load — vmcnt(0) — instead of for its own four)
+        // (fenced: left alone the scheduler reorders a group of loads and the first use waits for the last of them)
         __builtin_amdgcn_sched_barrier(0);
-        f.ah[0] = ws_load16(rs_a, v_dx[dx] + imm, so);
-        f.al[0] = ws_load16(rs_a, v_dx[dx] + imm + 1024u, so);
-        f.ah[1] = ws_load16(rs_a, v_dx[dx] + imm, so + 4096u);
-        f.al[1] = ws_load16(rs_a, v_dx[dx] + imm + 1024u, so + 4096u);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            f.h[b] = ws_load16(rs_a, v_lane + imm, so + (unsigned)b * 4096u);
+            f.l[b] = ws_load16(rs_a, v_lane + imm + 1024u, so + (unsigned)b * 4096u);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
-#ifdef SR3_EXPERIMENTS
     long long tl_a = 0, tl_b = 0, tl_c = 0, tl_k = 0, tl_e = 0, tl_n = 0;
     const long long tl_0 = (long long)__builtin_amdgcn_s_memtime();
     const long long tr_0 = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
     unsigned sb_cur = sub_base(tile * 128);
-    ws_static_for<WS_DEPTH>([&](auto kc) { issue(kc, sb_cur); });
-    {   // the first tile's rows (behind its first fragments, which the first K-step waits for)
-        const int m0 = tile * 128;
-        const int n = p.hw_shift >= 0 ? (m0 >> p.hw_shift) : m0 / HWo;
-        const int rem = m0 - n * HWo;
-        touch_rows(n, p.w_shift >= 0 ? (rem >> p.w_shift) : rem / W, min(rpt + 2, 15 / ipr));
-    }
+    ws_static_for<WS_RING>([&](auto gc) { issue(gc, sb_cur); });
     // The two waves of a SIMD (w and w + 4) would run in lock-step — both in their K loops (sharing the matrix pipe), then
     // both in their epilogues (pipe idle). Half a K loop of delay for the upper four lets one wave's epilogue run under
     // the other's MFMAs.
@@ -222,15 +201,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     for (; tile < tile_end; ++tile) {
         const int m_tile = tile * 128;
         const int img = p.hw_shift >= 0 ? (m_tile >> p.hw_shift) : m_tile / HWo;
-        // the rows the NEXT tile adds below this one's (its first rows too if it starts a new image)
-        if (tile + 1 < tile_end) {
-            const int m1 = m_tile + 128;
-            const int n1 = p.hw_shift >= 0 ? (m1 >> p.hw_shift) : m1 / HWo;
-            const int rem1 = m1 - n1 * HWo;
-            const int y1 = p.w_shift >= 0 ? (rem1 >> p.w_shift) : rem1 / W;
-            if (n1 == img) touch_rows(n1, y1 + 2, rpt);
-            else touch_rows(n1, y1, min(rpt + 2, 15 / ipr));
-        }
         // column bias of the tile: conv bias + FeatureWiseAffine bias of the tile's image (a tile never spans two images)
         float cb[4];
 #pragma unroll
@@ -252,39 +222,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
             WS_STAMP(tl_a)
-            // ---------------- halo K-steps: weights from LDS, A fragments from the register ring
-            ws_static_for<WS_KSTEPS>([&](auto ksc) {
-                constexpr int ks = decltype(ksc)::value;
-                const unsigned bh = lds0 + (unsigned)ks * 8192u + b_hi;
-                const unsigned bl = bh ^ 64u;
-                h16x8 bqh[4], bql[4];
+            // ---------------- halo K-steps: weights from LDS, A fragments from the block ring (dx = 0 as loaded, 1 and 2 by DPP)
+            ws_static_for<WS_GROUPS>([&](auto gic) {
+                constexpr int gi = decltype(gic)::value;
+                const WsGroup &f = ring[gi % WS_RING];
+                ws_static_for<3>([&](auto dxc) {
+                    constexpr int dx = decltype(dxc)::value;
+                    constexpr int ks = gi * 3 + dx;
+                    const unsigned bh = lds0 + (unsigned)ks * 8192u + b_hi;
+                    const unsigned bl = bh ^ 64u;
+                    h16x8 bqh[4], bql[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    bqh[nt] = *(lds_frag)(bh + nt * 2048);
-                    bql[nt] = *(lds_frag)(bl + nt * 2048);
-                }
-                const WsFrag &f = ring[ks % WS_DEPTH];
-                // term-major: the three products of one accumulator (al*bh, ah*bl, ah*bh — the x-halo kernel's order) are
-                // eight MFMAs apart, so no MFMA waits for the result of the one in front of it
+                    for (int nt = 0; nt < 4; ++nt) {
+                        bqh[nt] = *(lds_frag)(bh + nt * 2048);
+                        bql[nt] = *(lds_frag)(bl + nt * 2048);
+                    }
+                    h16x8 ah[2], al[2];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                    for (int mt = 0; mt < 2; ++mt) {
+                        ah[mt] = ws_shift<dx>(f.h[mt], f.h[mt + 1]);
+                        al[mt] = ws_shift<dx>(f.l[mt], f.l[mt + 1]);
+                    }
+                    // term-major: the three products of one accumulator (al*bh, ah*bl, ah*bh — the x-halo kernel's order) are
+                    // eight MFMAs apart, so no MFMA waits for the result of the one in front of it
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[mt], bql[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bql[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
-                // the MFMAs have read the ring slot: refill it with K-step ks + DEPTH of this sub-tile (the loads are
-                // issued while the matrix pipe works through the 24 MFMAs above)
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
+                });
+                // the group's registers are free: refill them with group gi + RING of this sub-tile, or with a group of the
+                // next sub-tile (its first three go out here, before the epilogue, and fly under it)
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ks + WS_DEPTH < WS_KSTEPS) issue(std::integral_constant<int, ks + WS_DEPTH>{}, sb_cur);
+                if constexpr (gi + WS_RING < WS_GROUPS) issue(std::integral_constant<int, gi + WS_RING>{}, sb_cur);
+                else if (!last_sub) issue(std::integral_constant<int, gi + WS_RING - WS_GROUPS>{}, sb_next);
                 __builtin_amdgcn_sched_barrier(0);
             });
             // ---------------- fused 1x1 K-steps (res_conv over x || skip, or the identity skip as 2^k I): both operands
@@ -327,10 +308,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                 }
             }
             WS_STAMP(tl_b)
-            // ---------------- the next sub-tile's first fragments go out BEFORE the epilogue and fly under it
-            if (!last_sub) {
-                ws_static_for<WS_DEPTH>([&](auto kc) { issue(kc, sb_next); });
-            }
             __builtin_amdgcn_sched_barrier(0);
             // ---------------- epilogue: C/D map col = l16 (+ 16 nt), row = 4 q + r (+ 16 mt)
             {
@@ -381,9 +358,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
             WS_STAMP(tl_c)
             WS_TL_ADD
         }
-        // (the touch loads of this tile were issued ~30 us ago and are older than every fragment load waited for since)
-#pragma unroll
-        for (int i = 0; i < 15; ++i) asm volatile("" ::"v"(tch[i]));
         // ---- statistics slice of the tile: add the four row groups (lanes q) in a fixed order, lanes q == 0 write
         if (p.stats != nullptr) {
             const int slice = p.stats_slice0 + (m_tile - img * HWo) / 128;
@@ -398,13 +372,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         }
     }
     if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
-#ifdef SR3_EXPERIMENTS
     if ((p.dbg & 64) && p.part != nullptr && lane == 0) {
         long long *o = reinterpret_cast<long long *>(p.part) + (size_t)g * 4;
         o[0] = tl_k; o[1] = tl_e; o[2] = (long long)__builtin_amdgcn_s_memtime() - tl_0;
         o[3] = tl_n | (((long long)__builtin_amdgcn_s_memrealtime() - tr_0) << 16);      // [15:0] sub-tiles, [63:16] 100 MHz ticks
     }
-#endif
 }
 
 }  // namespace
@@ -445,7 +417,6 @@ void launch_conv_ws(const ConvParams &p, hipStream_t s) {
     const int tiles = (int)((long)p.B * p.Hout * p.Wout / 128);
     const int waves = cus * WS_WAVES;
     const int tpw = (tiles + waves - 1) / waves;
-#ifdef SR3_EXPERIMENTS
     if (p.dbg & 64) {       // timeline run: a buffer of its own, synchronous, averages to stderr
         ConvParams q = p;
         long long *buf = nullptr;
@@ -466,7 +437,6 @@ void launch_conv_ws(const ConvParams &p, hipStream_t s) {
                     cnt, n / cnt, k / n, e / n, t / cnt, 100 * k / t, 100 * e / t, 100 * (t - k - e) / t, rt / cnt / 100.0, t / (rt / 100.0));
         return;
     }
-#endif
     hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, p, tiles, tpw);
 }
 

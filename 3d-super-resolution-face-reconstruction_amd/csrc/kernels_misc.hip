@@ -516,7 +516,9 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, con
     const int Hh = out.H / NR;
     const int n = blockIdx.y / Hh, y0 = blockIdx.y - n * Hh;
     const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= out.W * C8) return;
+    // (SPLIT 3: the launcher guarantees C == 64 and W % 32 == 0 — whole blocks, every thread reaches the barrier)
+    __shared__ h16x8 fm_stage[SPLIT == 3 ? NR * 8 * 2 * 32 : 1];
+    if (SPLIT != 3 && item >= out.W * C8) return;
     const int x = item / C8;
     const int c = (item - x * C8) << 3;
     const bool first = c < C0;
@@ -567,7 +569,39 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const TDesc in0, con
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = swish_fast(f[j]);
         }
-        store_out<SPLIT>(out, n, y, x, C, c, f, absmax);
+        if constexpr (SPLIT == 3) {
+            // Fragment-major output (C == 64, W % 32 == 0: a block is 32 consecutive pixels x 8 octets). Written straight
+            // from this thread mapping every quad would store four 16-byte pieces 256 B apart (+50 % on the whole pass:
+            // profiles/README.md finding 66), so the pieces go through LDS: thread (pixel pl, octet j) leaves hi | lo in
+            // slot [row][j][h][pl]; after the barrier thread t picks up (j = t >> 5, pl = t & 31) — a quad then writes
+            // 64 consecutive bytes of one (chunk, h, q) run of the FM block.
+            h16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = f[j];
+                absmax = fmaxf(absmax, fabsf(g));
+                hi[j] = (_Float16)g;
+                lo[j] = (_Float16)(g - (float)hi[j]);
+            }
+            const int pl = threadIdx.x >> 3, jo = threadIdx.x & 7;
+            fm_stage[((r * 8 + jo) * 2 + 0) * 32 + pl] = hi;
+            fm_stage[((r * 8 + jo) * 2 + 1) * 32 + pl] = lo;
+        } else {
+            store_out<SPLIT>(out, n, y, x, C, c, f, absmax);
+        }
+    }
+    if constexpr (SPLIT == 3) {
+        __syncthreads();
+        const int jo = threadIdx.x >> 5, pl = threadIdx.x & 31;
+        const int xq = blockIdx.x * 32 + pl + 1;                    // padded x of this thread's output pixel
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int yp = y0 + r * Hh + 1;
+            const size_t blk = (((size_t)n * (out.H + 2) + yp) * fm_groups(out.W) + (xq >> 4)) * 2 + (jo >> 2);
+            char *d = reinterpret_cast<char *>(out.p) + blk * 2048 + (jo & 3) * 256 + (xq & 15) * 16;
+            *reinterpret_cast<h16x8 *>(d) = fm_stage[((r * 8 + jo) * 2 + 0) * 32 + pl];
+            *reinterpret_cast<h16x8 *>(d + 1024) = fm_stage[((r * 8 + jo) * 2 + 1) * 32 + pl];
+        }
     }
     if (SPLIT && ovf != nullptr && (absmax > (SPLIT == 2 ? SPLIT_F8_MAX : SPLIT_F16_MAX) || absmax_raw > SPLIT_F16_MAX)) *ovf = 1;
 }

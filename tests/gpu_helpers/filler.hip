@@ -26,14 +26,24 @@ __global__ __launch_bounds__(64) void poke_kernel(int *word, int bits, long long
     if (threadIdx.x == 0) atomicOr(word, bits);
 }
 
+// The helper's stream must not share a hardware queue with the stream of the library under test (ROCm maps streams onto a
+// few hardware queues round-robin; two streams on one queue execute in submission order — no co-tenancy at all, and a poke
+// submitted first would land before the call it is meant to interrupt). Streams of a different PRIORITY get queues of
+// their own, so the helper's is created with the highest one.
 static hipStream_t g_stream = nullptr;
+static bool make_stream() {
+    if (g_stream) return true;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (numerically lowest = highest priority)
+    return hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, hi) == hipSuccess;
+}
 static unsigned *g_started = nullptr;      // host-visible counter of blocks that have begun to run
 
 extern "C" {
 
 // launches `blocks` holders of `lds_bytes` LDS each for `ticks` x 10 ns on a stream of their own; returns 0 on success
 int filler_launch(int blocks, int lds_bytes, long long ticks) {
-    if (!g_stream && hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!make_stream()) return -1;
     if (!g_started && hipHostMalloc(reinterpret_cast<void **>(&g_started), sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return -2;
     *g_started = 0;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(hold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return -3;
@@ -41,7 +51,7 @@ int filler_launch(int blocks, int lds_bytes, long long ticks) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int filler_poke(void *word, int bits, long long ticks) {
-    if (!g_stream && hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!make_stream()) return -1;
     hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(64), 0, g_stream, reinterpret_cast<int *>(word), bits, ticks);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -210,7 +210,7 @@ def test_inplace_splitk_with_cotenant_holding_the_cus():
           f"warnings {[type(v.message).__name__ for v in wlist]}")
     assert dt < 5.0                                      # bounded: 300 ms of holders (~2 x 60 waits of 5 ms under them) + the replay
     assert np.abs(busy - want).max() < 2e-5
-    assert np.abs(busy - calm).max() < 2e-6              # (split vs unsplit K order: fp32 summation order only)
+    assert np.abs(busy - calm).max() < 2e-5              # (split vs unsplit K order over K = 4608: fp32 summation order only)
     if replays:
         assert any(isinstance(v.message, Sr3ReplayWarning) for v in wlist)
         # the context stays on the non-waiting path: another disturbed conv needs no replay any more
@@ -397,7 +397,7 @@ def test_two_ranks_of_32_images_fp8_path_on():
 # ------------------------------------------------------------------------------------------------------------------
 # the 64 -> 64 channel convs of the full-resolution level
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", [(16, 128, 128), (64, 128, 128), (64, 64, 64), (22, 96, 128)])
+@pytest.mark.parametrize("case", [(16, 128, 128), (64, 128, 128), (64, 64, 64), (22, 96, 128), (33, 128, 128)])
 def test_conv_64_to_64_full_resolution_vs_oracle(case):
     """3x3 / stride 1 / 64 -> 64 channels over >= 2048 tiles of 128 pixels (unet.py:80-91 `Block` conv at the 128x128
     level: 2.1 ms of the B = 64 step, the shapes furthest below the roofline). With bias and the per-image

@@ -8,6 +8,7 @@ bash tools/profile_round.sh f16x3 > gpurun_out/pr_f16x3.log 2>&1
 bash tools/profile_round.sh f32 > gpurun_out/pr_f32.log 2>&1
 python tools/step_profile.py --batch 64 --steps 20 --precision f16f8 --csv gpurun_out/conv_shapes_f16f8.csv > gpurun_out/sp64.txt 2>&1
 python tools/step_profile.py --batch 64 --steps 20 --precision f16x3 --csv gpurun_out/conv_shapes_f16x3.csv >> gpurun_out/sp64.txt 2>&1
+python tools/step_profile.py --batch 64 --steps 10 --precision f32 --csv gpurun_out/conv_shapes_f32.csv >> gpurun_out/sp64.txt 2>&1
 python bench.py > gpurun_out/bench_full.log 2>&1
 : > gpurun_out/configs.txt
 run_cfg() { echo "== bench.py $*" >> gpurun_out/configs.txt; python bench.py "$@" --no-cpu-baseline 2>/dev/null | tail -n 1 >> gpurun_out/configs.txt; }

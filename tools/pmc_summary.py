@@ -26,7 +26,11 @@ def family(name):
                      # copyBuffer launches of a bench run are the staged host-to-device uploads of the 349 weight
                      # tensors, all in front of the first step; the fills zero the workspace) — never part of a step
                      ("__amd_rocclr_", "setup_once"), ("pack_state", "setup_once"), ("init_state", "setup_once"),
-                     ("nchw_to_nhwc", "setup_once"), ("nhwc_to_nchw", "setup_once")):
+                     ("nchw_to_nhwc", "setup_once"),
+                     # PER-CALL work: the final copy-out and, in the split-f16 modes, sr3_sample's checkpoint copies of the
+                     # sampler state at every segment boundary (~10 per call) — not part of a step, but not
+                     # "once" either: reported as a family of its own
+                     ("nhwc_to_nchw", "per_call_copies")):
         if key in name:
             return fam
     return "other"
