@@ -45,6 +45,7 @@ void launch_conv_ws(const ConvParams &, hipStream_t) {}
 #else
 
 #include <stdio.h>
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -61,7 +62,12 @@ constexpr int WS_KSTEPS = 18;                  // 9 taps x 2 chunks of 32 channe
 constexpr int WS_LDS_BYTES = WS_KSTEPS * WS_C * 128;      // 147,456
 constexpr int WS_WAVES = 8;
 constexpr int WS_GROUPS = 6;                   // (chunk, dy) groups of a sub-tile: three K-steps (dx) each
-constexpr int WS_RING = 3;                     // groups of A blocks in registers per wave (24 registers each)
+#ifndef SR3_WS_MT
+#define SR3_WS_MT 4
+#endif
+constexpr int WS_MT = SR3_WS_MT;               // 16-pixel row tiles per wave sub-tile: 2 (32 pixels) or 4 (64 pixels)
+constexpr int WS_SUBPIX = 16 * WS_MT, WS_NSUB = 128 / WS_SUBPIX;
+constexpr int WS_RING = WS_MT == 2 ? 3 : 2;    // groups of A blocks in registers per wave (8 (MT + 1) registers each)
 
 template <int N, class F>
 __device__ __forceinline__ void ws_static_for(F &&f) {
@@ -76,9 +82,9 @@ __device__ __forceinline__ u32x4 ws_load16(const __amdgpu_buffer_rsrc_t rsrc, un
 }
 
 // The A operand of one (chunk, dy) group: three 16-pixel blocks of the fragment-major tensor (pixels x0 .. x0 + 47 of the
-// padded row; the third only for its first two pixels), hi and lo halfs — each block is 1 KB of consecutive memory and
+// padded row; the last one only for its first two pixels: MT + 1 blocks for MT row tiles), hi and lo halfs — each block is 1 KB of consecutive memory and
 // IS the MFMA fragment of its 16 pixels for tap dx = 0 (lane (l16, q) = slot q * 16 + l16 of the block).
-struct WsGroup { u32x4 h[3], l[3]; };
+struct WsGroup { u32x4 h[WS_MT + 1], l[WS_MT + 1]; };
 
 // Fragment of a row tile for tap dx from the aligned blocks: lane l16 needs pixel l16 + dx of block `a`, or pixel
 // l16 + dx - 16 of the next block `nx`. The 16 lanes of one q are one DPP row, so a pixel shift is a row shift: two DPP
@@ -100,8 +106,17 @@ __device__ __forceinline__ h16x8 ws_shift(const u32x4 a, const u32x4 nx) {
 
 // In-kernel timeline (ConvParams::dbg bit 6): per wave the shader cycles spent in the K loops (halo + fused 1x1 K-steps), in
 // the epilogues and in total, the sub-tile count and the 100 MHz real-time ticks — launch_conv_ws prints the averages
+// (a build of its own, -DSR3_WS_TIMELINE=1: the counters cost 14 registers the 64-pixel form does not have)
+#ifndef SR3_WS_TIMELINE
+#define SR3_WS_TIMELINE 0
+#endif
+#if SR3_WS_TIMELINE
 #define WS_STAMP(v) if (p.dbg & 64) { v = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 #define WS_TL_ADD if (p.dbg & 64) { tl_k += tl_b - tl_a; tl_e += tl_c - tl_b; ++tl_n; }
+#else
+#define WS_STAMP(v)
+#define WS_TL_ADD
+#endif
 
 // One persistent block per CU, 8 waves. Tiles of 128 consecutive output pixels (whole tiles per image; W is 32, 64 or 128,
 // so a tile is 4, 2 or 1 whole image rows and a 32-pixel sub-tile never leaves its row).
@@ -112,6 +127,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int l16 = lane & 15, q = lane >> 4;
+#if SR3_WS_TIMELINE
+    const long long tr_launch = (long long)__builtin_amdgcn_s_memrealtime();      // (timeline: the wave's first instruction)
+#endif
 
     // ---- weights -> LDS, once: row R = kstep * 64 + cout (128 B = 32 hi halfs | 32 lo halfs of one 32-channel chunk),
     //      16-byte slot s of a row holds source chunk s ^ ((cout >> 1) & 7) (conflict-free ds_read_b128 of the fragments).
@@ -181,16 +199,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         // (fenced: left alone the scheduler reorders a group of loads and the first use waits for the last of them)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
+        for (int b = 0; b < WS_MT + 1; ++b) {
             f.h[b] = ws_load16(rs_a, v_lane + imm, so + (unsigned)b * 4096u);
             f.l[b] = ws_load16(rs_a, v_lane + imm + 1024u, so + (unsigned)b * 4096u);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
 
+#if SR3_WS_TIMELINE
     long long tl_a = 0, tl_b = 0, tl_c = 0, tl_k = 0, tl_e = 0, tl_n = 0;
     const long long tl_0 = (long long)__builtin_amdgcn_s_memtime();
     const long long tr_0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     unsigned sb_cur = sub_base(tile * 128);
     ws_static_for<WS_RING>([&](auto gc) { issue(gc, sb_cur); });
     // The two waves of a SIMD (w and w + 4) would run in lock-step — both in their K loops (sharing the matrix pipe), then
@@ -210,13 +230,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
             cb[nt] = v;
         }
         double st1[4] = {0, 0, 0, 0}, st2[4] = {0, 0, 0, 0};
-        for (int sub = 0; sub < 4; ++sub) {
-            const int m_sub = m_tile + sub * 32;
-            const bool last_sub = sub == 3 && tile + 1 >= tile_end;
-            const unsigned sb_next = last_sub ? sb_cur : sub_base(m_sub + 32);      // (tiles of a wave are consecutive)
-            f32x4 acc[2][4];
+        for (int sub = 0; sub < WS_NSUB; ++sub) {
+            const int m_sub = m_tile + sub * WS_SUBPIX;
+            const bool last_sub = sub == WS_NSUB - 1 && tile + 1 >= tile_end;
+            const unsigned sb_next = last_sub ? sb_cur : sub_base(m_sub + WS_SUBPIX);      // (tiles of a wave are consecutive)
+            f32x4 acc[WS_MT][4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < WS_MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -237,29 +257,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                         bqh[nt] = *(lds_frag)(bh + nt * 2048);
                         bql[nt] = *(lds_frag)(bl + nt * 2048);
                     }
-                    h16x8 ah[2], al[2];
+                    // row tile by row tile: its two shifted fragments (8 registers) are made right in front of their twelve
+                    // MFMAs; within a row tile the three products of one accumulator (al*bh, ah*bl, ah*bh — the x-halo kernel's
+                    // order) are four MFMAs apart, so no MFMA waits for the result of the one in front of it
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        ah[mt] = ws_shift<dx>(f.h[mt], f.h[mt + 1]);
-                        al[mt] = ws_shift<dx>(f.l[mt], f.l[mt + 1]);
+                    for (int mt = 0; mt < WS_MT; ++mt) {
+                        const h16x8 ah = ws_shift<dx>(f.h[mt], f.h[mt + 1]);
+                        const h16x8 al = ws_shift<dx>(f.l[mt], f.l[mt + 1]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bqh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bql[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bqh[nt], acc[mt][nt], 0, 0, 0);
                     }
-                    // term-major: the three products of one accumulator (al*bh, ah*bl, ah*bh — the x-halo kernel's order) are
-                    // eight MFMAs apart, so no MFMA waits for the result of the one in front of it
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bql[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
                 });
                 // the group's registers are free: refill them with group gi + RING of this sub-tile, or with a group of the
                 // next sub-tile (its first three go out here, before the epilogue, and fly under it)
@@ -283,13 +297,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                                            : reinterpret_cast<const char *>(p.in2b.p + (c0 - C2a));
                     const unsigned Cs = first ? (unsigned)C2a : (unsigned)(C2 - C2a);
                     const unsigned pix = first ? pixa : (unsigned)p.in2b.pix(n, y, x0 + l16);
-                    h16x8 ah[2], al[2], bqh[4], bql[4];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const char *a = ab + ((size_t)(pix + mt * 16) * Cs) * 4 + q * 16;
-                        ah[mt] = *reinterpret_cast<const h16x8 *>(a);
-                        al[mt] = *reinterpret_cast<const h16x8 *>(a + 64);
-                    }
+                    h16x8 bqh[4], bql[4];
                     const char *wb = reinterpret_cast<const char *>(p.w2 + c0) + q * 16;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
@@ -297,14 +305,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                         bqh[nt] = *reinterpret_cast<const h16x8 *>(b);
                         bql[nt] = *reinterpret_cast<const h16x8 *>(b + 64);
                     }
+                    // (row tile by row tile: 8 operand registers at a time; these few K-steps are not software-pipelined)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                    for (int mt = 0; mt < WS_MT; ++mt) {
+                        const char *a = ab + ((size_t)(pix + mt * 16) * Cs) * 4 + q * 16;
+                        const h16x8 ah = *reinterpret_cast<const h16x8 *>(a);
+                        const h16x8 al = *reinterpret_cast<const h16x8 *>(a + 64);
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bql[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bqh[nt], acc[mt][nt], 0, 0, 0);
-                        }
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bqh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bql[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bqh[nt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
             WS_STAMP(tl_b)
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < WS_MT; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = fmaf(acc[mt][nt][r], p.w_unscale, cb[nt]);
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                 if (p.out_f32) {
                     char *obase = reinterpret_cast<char *>(p.out.p);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < WS_MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
                     for (int nt = 0; nt < 4; ++nt) {
                         const unsigned coff = ((unsigned)(nt >> 1) * 32u + (unsigned)(nt & 1) * 8u) * 4u;
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
+                        for (int mt = 0; mt < WS_MT; ++mt)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const unsigned word = split_pair_word(acc[mt][nt][r], psel, range_bits);
@@ -372,11 +388,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         }
     }
     if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
+#if SR3_WS_TIMELINE
     if ((p.dbg & 64) && p.part != nullptr && lane == 0) {
-        long long *o = reinterpret_cast<long long *>(p.part) + (size_t)g * 4;
+        long long *o = reinterpret_cast<long long *>(p.part) + (size_t)g * 8;
+        const long long tr_end = (long long)__builtin_amdgcn_s_memrealtime();
         o[0] = tl_k; o[1] = tl_e; o[2] = (long long)__builtin_amdgcn_s_memtime() - tl_0;
-        o[3] = tl_n | (((long long)__builtin_amdgcn_s_memrealtime() - tr_0) << 16);      // [15:0] sub-tiles, [63:16] 100 MHz ticks
+        o[3] = tl_n | ((tr_end - tr_0) << 16);      // [15:0] sub-tiles, [63:16] 100 MHz ticks
+        o[4] = tr_launch; o[5] = tr_0; o[6] = tr_end;       // absolute 100 MHz stamps: first instruction, after the barrier, end
     }
+#endif
 }
 
 }  // namespace
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
 bool conv_ws_shape_ok(int B, int H, int W, int Cin, int Cout) {
     static const int on = exp_int("SR3_WS", 0);
     if (!on || env_int("SR3_NO_HALO", 0) || Cin != WS_C || Cout != WS_C) return false;
-    if (!(W == 32 || W == 64 || W == 128) || ((H * W) % 128) != 0) return false;
+    if (!(W == 32 || W == 64 || W == 128) || W < WS_SUBPIX || ((H * W) % 128) != 0) return false;
     // at least one 128-pixel tile for every wave of a chip-wide launch (each block loads the 144 KB weight tensor once)
     return (long)B * H * W / 128 >= 2048 && fm_floats(B, WS_C, H, W) * sizeof(float) < (1ull << 32);
 }
@@ -417,24 +437,37 @@ void launch_conv_ws(const ConvParams &p, hipStream_t s) {
     const int tiles = (int)((long)p.B * p.Hout * p.Wout / 128);
     const int waves = cus * WS_WAVES;
     const int tpw = (tiles + waves - 1) / waves;
-    if (p.dbg & 64) {       // timeline run: a buffer of its own, synchronous, averages to stderr
+    if (SR3_WS_TIMELINE && (p.dbg & 64)) {       // timeline run: a buffer of its own, synchronous, averages to stderr
         ConvParams q = p;
         long long *buf = nullptr;
-        (void)hipMalloc(&buf, (size_t)waves * 4 * sizeof(long long));
-        (void)hipMemset(buf, 0, (size_t)waves * 4 * sizeof(long long));
+        (void)hipMalloc(&buf, (size_t)waves * 8 * sizeof(long long));
+        (void)hipMemset(buf, 0, (size_t)waves * 8 * sizeof(long long));
         q.part = reinterpret_cast<float *>(buf);
         hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, q, tiles, tpw);
         (void)hipStreamSynchronize(s);
-        std::vector<long long> h((size_t)waves * 4);
+        std::vector<long long> h((size_t)waves * 8);
         (void)hipMemcpy(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         (void)hipFree(buf);
         double k = 0, e = 0, t = 0, n = 0, rt = 0; int cnt = 0;
-        for (int i = 0; i < waves; ++i) if (h[i * 4 + 3] > 0) { k += h[i * 4]; e += h[i * 4 + 1]; t += h[i * 4 + 2]; n += h[i * 4 + 3] & 0xFFFF; rt += (double)(h[i * 4 + 3] >> 16); ++cnt; }
+        long long t_first = 0, t_last_start = 0, t_bar_min = 0, t_bar_max = 0, t_end_min = 0, t_end_max = 0;
+        for (int i = 0; i < waves; ++i) if (h[i * 8 + 3] > 0) {
+            k += h[i * 8]; e += h[i * 8 + 1]; t += h[i * 8 + 2]; n += h[i * 8 + 3] & 0xFFFF; rt += (double)(h[i * 8 + 3] >> 16);
+            const long long a = h[i * 8 + 4], b = h[i * 8 + 5], c2 = h[i * 8 + 6];
+            if (!cnt) { t_first = t_last_start = a; t_bar_min = t_bar_max = b; t_end_min = t_end_max = c2; }
+            t_first = std::min(t_first, a); t_last_start = std::max(t_last_start, a);
+            t_bar_min = std::min(t_bar_min, b); t_bar_max = std::max(t_bar_max, b);
+            t_end_min = std::min(t_end_min, c2); t_end_max = std::max(t_end_max, c2);
+            ++cnt;
+        }
         static int printed = 0;
         if (cnt && printed++ < 3)
             fprintf(stderr, "ws timeline: %d waves, %.1f sub-tiles each; per sub-tile K loop %.0f cycles, epilogue %.0f; per wave total %.0f cycles "
                     "(K %.1f %%, epilogue %.1f %%, rest = weight load + first loads %.1f %%); %.1f us per wave on the 100 MHz counter => s_memtime ticks at %.0f MHz\n",
                     cnt, n / cnt, k / n, e / n, t / cnt, 100 * k / t, 100 * e / t, 100 * (t - k - e) / t, rt / cnt / 100.0, t / (rt / 100.0));
+        if (cnt && printed <= 3)
+            fprintf(stderr, "ws launch timeline (us from the first wave's first instruction): last wave starts %.1f; barrier passed %.1f .. %.1f; "
+                    "waves end %.1f .. %.1f\n", (t_last_start - t_first) / 100.0, (t_bar_min - t_first) / 100.0, (t_bar_max - t_first) / 100.0,
+                    (t_end_min - t_first) / 100.0, (t_end_max - t_first) / 100.0);
         return;
     }
     hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, p, tiles, tpw);
