@@ -60,14 +60,25 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS_C = 64;                       // Cin == Cout == 64
 constexpr int WS_KSTEPS = 18;                  // 9 taps x 2 chunks of 32 channels
 constexpr int WS_LDS_BYTES = WS_KSTEPS * WS_C * 128;      // 147,456
-constexpr int WS_WAVES = 8;
+#ifndef SR3_WS_WAVES
+#define SR3_WS_WAVES 8
+#endif
+constexpr int WS_WAVES = SR3_WS_WAVES;         // 8 (two per SIMD, 256 registers), 12 (three, 168) or 16 (four, 128)
+constexpr int WS_THREADS = WS_WAVES * 64;
+#ifndef SR3_WS_DYN
+#define SR3_WS_DYN 1
+#endif
+constexpr bool WS_DYN = SR3_WS_DYN != 0;       // tiles handed out by per-XCD counters (ConvParams::tile_cnt) instead of statically
 constexpr int WS_GROUPS = 6;                   // (chunk, dy) groups of a sub-tile: three K-steps (dx) each
 #ifndef SR3_WS_MT
 #define SR3_WS_MT 4
 #endif
 constexpr int WS_MT = SR3_WS_MT;               // 16-pixel row tiles per wave sub-tile: 2 (32 pixels) or 4 (64 pixels)
 constexpr int WS_SUBPIX = 16 * WS_MT, WS_NSUB = 128 / WS_SUBPIX;
-constexpr int WS_RING = WS_MT == 2 ? 3 : 2;    // groups of A blocks in registers per wave (8 (MT + 1) registers each)
+#ifndef SR3_WS_RING
+#define SR3_WS_RING (SR3_WS_MT == 2 ? 3 : 2)
+#endif
+constexpr int WS_RING = SR3_WS_RING;           // groups of A blocks in registers per wave (8 (MT + 1) registers each): 2 or 3
 
 template <int N, class F>
 __device__ __forceinline__ void ws_static_for(F &&f) {
@@ -121,7 +132,7 @@ __device__ __forceinline__ h16x8 ws_shift(const u32x4 a, const u32x4 nx) {
 // One persistent block per CU, 8 waves. Tiles of 128 consecutive output pixels (whole tiles per image; W is 32, 64 or 128,
 // so a tile is 4, 2 or 1 whole image rows and a 32-pixel sub-tile never leaves its row).
 // Wave g (XCD-major numbering, so that the tiles of an image stay in one XCD's L2) takes tiles [g * tpw, (g + 1) * tpw).
-__global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p, const int tiles_total, const int tpw) {
+__global__ __launch_bounds__(WS_THREADS, WS_WAVES / 4) void conv3x3_ws64_kernel(const ConvParams p, const int tiles_total, const int tpw) {
     extern __shared__ __attribute__((aligned(128))) float wlds[];
     const int tid = threadIdx.x;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,18 +147,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     //      All 18 loads of a thread are in flight before the first LDS write (one round trip, L2-resident after the first block).
     {
         const char *wsrc = reinterpret_cast<const char *>(p.w);
-        u32x4 wv[WS_LDS_BYTES / (512 * 16)];
+        u32x4 wv[WS_LDS_BYTES / (WS_THREADS * 16)];
 #pragma unroll
-        for (int i = 0; i < WS_LDS_BYTES / (512 * 16); ++i) {
-            const int L = i * 512 + tid;
+        for (int i = 0; i < WS_LDS_BYTES / (WS_THREADS * 16); ++i) {
+            const int L = i * WS_THREADS + tid;
             const int R = L >> 3, s = L & 7;
             const int ks = R >> 6, o = R & 63;
             const int chunk = ks / 9, tap = ks - chunk * 9;      // K-step order of the consumers: chunk-major, then the tap
             wv[i] = *reinterpret_cast<const u32x4 *>(wsrc + ((size_t)(tap * WS_C + o) * WS_C + chunk * 32) * 4 + ((s ^ ((o >> 1) & 7)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < WS_LDS_BYTES / (512 * 16); ++i) {
-            const int L = i * 512 + tid;
+        for (int i = 0; i < WS_LDS_BYTES / (WS_THREADS * 16); ++i) {
+            const int L = i * WS_THREADS + tid;
             *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(wlds) + (L >> 3) * 128 + (L & 7) * 16) = wv[i];
         }
     }
@@ -158,9 +169,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     const int xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
     const int per_xcd = (nblk + 7) >> 3;
     const int g = (xcd * per_xcd + loc) * WS_WAVES + wid;
-    int tile = g * tpw;
-    const int tile_end = min(tile + tpw, tiles_total);
-    if (tile >= tile_end) return;
+    // static: wave g takes tiles [g * tpw, (g + 1) * tpw). dynamic (WS_DYN): XCD x owns tiles [x * tpx, (x + 1) * tpx) and its
+    // waves take them one at a time from the XCD's counter (ConvParams::tile_cnt[x]; word 8 counts finished waves: the last
+    // one leaves all nine words at zero for the next launch) — the waves of a launch then finish together whatever their
+    // luck with the matrix pipe and the memory system (static: wave end times spread over 148 … 213 us)
+    const int tpx = (tiles_total + 7) >> 3;
+    auto grab = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = (int)__hip_atomic_fetch_add(p.tile_cnt + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int gt = xcd * tpx + t;
+        return (t < tpx && gt < tiles_total) ? gt : -1;
+    };
+    auto wave_done = [&]() {
+        if (WS_DYN && lane == 0) {
+            const unsigned total = gridDim.x * WS_WAVES;
+            const unsigned old = __hip_atomic_fetch_add(p.tile_cnt + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == total - 1u)
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(p.tile_cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    int tile = WS_DYN ? grab() : g * tpw;
+    const int tile_end = WS_DYN ? tiles_total : min(tile + tpw, tiles_total);
+    if (tile < 0 || tile >= tile_end) { wave_done(); return; }
+    int tile_next = -1;
 
     const int W = p.Wout, HWo = p.Hout * W;
     const int Hp = p.in0.Hp();
@@ -216,9 +248,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
     // The two waves of a SIMD (w and w + 4) would run in lock-step — both in their K loops (sharing the matrix pipe), then
     // both in their epilogues (pipe idle). Half a K loop of delay for the upper four lets one wave's epilogue run under
     // the other's MFMAs.
-    if (wid >= 4) __builtin_amdgcn_s_sleep(56);
+    if (wid >= 12) __builtin_amdgcn_s_sleep(120);
+    else if (wid >= 8) __builtin_amdgcn_s_sleep(80);
+    else if (wid >= 4) __builtin_amdgcn_s_sleep(40);
 
-    for (; tile < tile_end; ++tile) {
+    for (; tile >= 0 && tile < tile_end; tile = tile_next) {
+        // the tile after this one: the next of the static range, or the XCD counter's (taken now: its latency hides under the tile)
+        tile_next = WS_DYN ? grab() : (tile + 1 < tile_end ? tile + 1 : -1);
         const int m_tile = tile * 128;
         const int img = p.hw_shift >= 0 ? (m_tile >> p.hw_shift) : m_tile / HWo;
         // column bias of the tile: conv bias + FeatureWiseAffine bias of the tile's image (a tile never spans two images)
@@ -232,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         double st1[4] = {0, 0, 0, 0}, st2[4] = {0, 0, 0, 0};
         for (int sub = 0; sub < WS_NSUB; ++sub) {
             const int m_sub = m_tile + sub * WS_SUBPIX;
-            const bool last_sub = sub == WS_NSUB - 1 && tile + 1 >= tile_end;
-            const unsigned sb_next = last_sub ? sb_cur : sub_base(m_sub + WS_SUBPIX);      // (tiles of a wave are consecutive)
+            const bool last_sub = sub == WS_NSUB - 1 && tile_next < 0;
+            const unsigned sb_next = last_sub ? sb_cur : sub_base(sub == WS_NSUB - 1 ? tile_next * 128 : m_sub + WS_SUBPIX);
             f32x4 acc[WS_MT][4];
 #pragma unroll
             for (int mt = 0; mt < WS_MT; ++mt)
@@ -388,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const ConvParams p
         }
     }
     if (p.ovf != nullptr && split_range_overflow(range_bits)) *p.ovf = 1;
+    wave_done();
 #if SR3_WS_TIMELINE
     if ((p.dbg & 64) && p.part != nullptr && lane == 0) {
         long long *o = reinterpret_cast<long long *>(p.part) + (size_t)g * 8;
@@ -421,6 +458,7 @@ bool conv_ws_supported(const ConvParams &p) {
     if (p.in2.p && ((p.in2.C % 32) != 0 || p.in2.H != p.Hout || p.in2.W != W)) return false;
     if (p.in2b.p && (!p.in2.p || (p.in2b.C % 32) != 0 || p.in2b.H != p.Hout || p.in2b.W != W)) return false;
     if (p.in2.p && p.w2 == nullptr) return false;
+    if (WS_DYN && p.tile_cnt == nullptr) return false;
     return p.stats == nullptr || p.stats_slices == HWo / 128;
 }
 
@@ -443,7 +481,7 @@ void launch_conv_ws(const ConvParams &p, hipStream_t s) {
         (void)hipMalloc(&buf, (size_t)waves * 8 * sizeof(long long));
         (void)hipMemset(buf, 0, (size_t)waves * 8 * sizeof(long long));
         q.part = reinterpret_cast<float *>(buf);
-        hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, q, tiles, tpw);
+        hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(WS_THREADS), WS_LDS_BYTES, s, q, tiles, tpw);
         (void)hipStreamSynchronize(s);
         std::vector<long long> h((size_t)waves * 8);
         (void)hipMemcpy(h.data(), buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -470,7 +508,7 @@ void launch_conv_ws(const ConvParams &p, hipStream_t s) {
                     (t_end_min - t_first) / 100.0, (t_end_max - t_first) / 100.0);
         return;
     }
-    hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(512), WS_LDS_BYTES, s, p, tiles, tpw);
+    hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(cus), dim3(WS_THREADS), WS_LDS_BYTES, s, p, tiles, tpw);
 }
 
 }  // namespace sr3

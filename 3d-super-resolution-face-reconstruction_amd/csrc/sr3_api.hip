@@ -1756,6 +1756,7 @@ int sr3_op_conv2d(sr3_ctx *c, const float *in0_dev, int C0, const float *in1_dev
     p.ks = ks; p.stride = stride; p.up2 = up2;
     p.prec = c->prec; p.w_unscale = w_unscale; p.f8 = f8 ? 1 : 0;
     p.in_fm = ws ? 1 : 0;
+    if (ws) p.tile_cnt = c->tile_cnt;       // (the experiment's tile counters)
     p.w = dw; p.bias = db; p.chan_bias = chan_bias_dev; p.chan_bias_stride = Cout;
     p.out = unpadded(out_dev, Cout, p.Hout, p.Wout);
     p.ovf = c->d_ovf;            // (range bits of twin stores and the 'wait gave up' bit of the in-place split-K)
@@ -1836,6 +1837,7 @@ int sr3_bench_conv(sr3_ctx *c, int B, int Hin, int Win, int C0, int C1, int Cout
     const bool f8 = c->prec == 1 && c->f8corr && ks == 3 && stride == 1 && !up2 && conv_f8_supported(B, Hin, Win, Cout, Cin);
     p.f8 = f8 ? 1 : 0;       // (timing: the operand bytes are random either way)
     p.in_fm = ws_probe ? 1 : 0;
+    if (ws_probe) p.tile_cnt = c->tile_cnt;
     p.chan_bias = with_chan_bias ? cb : nullptr; p.chan_bias_stride = Cout;
     if (with_resid) p.resid = res;
     p.out = out;
