@@ -162,3 +162,21 @@ def test_ssim_matches_independent_scipy_evaluation():
     assert abs(val.calculate_ssim(rgb_a, rgb_b) - (val.ssim(a, b) + 2) / 3) < 1e-12
     with pytest.raises(ValueError):
         val.calculate_ssim(a, b[:-1])
+
+
+def test_chunk_plan_equal_chunks():
+    """Batches above one library call's limit (sr3_max_batch: every activation tensor < 4 GiB) are split by the facade into
+    the fewest EQUAL chunks, the last one padded (diffusion.GaussianDiffusion.chunk_plan): one workspace, one captured graph and
+    the same kernels for every chunk (lib/trainer_temp.py:441-446 stacks 15 samples x N images; configs[3] is 512 images)."""
+    G = pkg("diffusion").GaussianDiffusion
+    assert G.chunk_plan(64, 330) == (1, 64)
+    assert G.chunk_plan(330, 330) == (1, 330)
+    assert G.chunk_plan(331, 330) == (2, 166)
+    assert G.chunk_plan(400, 330) == (2, 200)
+    assert G.chunk_plan(512, 330) == (2, 256)
+    assert G.chunk_plan(960, 250) == (4, 240)
+    for B in range(1, 1200, 7):
+        for limit in (1, 3, 100, 330):
+            n, chunk = G.chunk_plan(B, limit)
+            assert chunk <= max(limit, 1) and n * chunk >= B and (n - 1) * chunk < B
+            assert n == -(-B // limit)              # fewest chunks
