@@ -204,14 +204,31 @@ def full_loop(eng, torch, B, r, T, cond, sec_per_step, precision):
             "note": "one sr3_sample call: init + T steps (hipGraph replay) + frame copies + final copy, host-timed"}
 
 
-def pmc_traffic(precision):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC summary (tools/pmc_summary.py),
-    corrected as MI355X_MICROARCH.md prescribes; None if no summary for this precision."""
+def pmc_summary(precision):
+    """The committed rocprofv3 PMC summary of this arithmetic mode (tools/pmc_summary.py; counters collected and
+    corrected as MI355X_MICROARCH.md prescribes, separate --pmc passes); None if there is none."""
     path = os.path.join(ROOT, "profiles", f"pmc_latest_{precision}.json")
     try:
         with open(path) as f:
-            # HBM bytes of the conv family per sampler step (PMC FETCH_SIZE / WRITE_SIZE passes)
-            return json.load(f)["per_step"]["conv_igemm"]["hbm_bytes"]
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def pmc_traffic(precision):
+    """HBM bytes of the conv family per sampler step (PMC FETCH_SIZE / WRITE_SIZE passes)"""
+    d = pmc_summary(precision)
+    try:
+        return d["per_step"]["conv_igemm"]["hbm_bytes"]
+    except Exception:
+        return None
+
+
+def pmc_mfma_busy(precision):
+    """SQ_VALU_MFMA_BUSY_CYCLES over the SIMD cycles of the conv family (north_star's 'MFMA utilisation', target >= 0.40)"""
+    d = pmc_summary(precision)
+    try:
+        return d["sq"]["conv_igemm"]["mfma_busy_frac_of_simd_cycles"]
     except Exception:
         return None
 
@@ -335,6 +352,9 @@ def main():
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": (traffic / (n / steps)) if traffic else None,
             "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC summary profiles/pmc_latest_%s.json)" % precision,
+            "mfma_pipe_busy": pmc_mfma_busy(precision),
+            "mfma_pipe_busy_note": ("SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles over the conv family, from the same committed PMC summary "
+                                    "(north_star's MFMA-utilisation target: >= 0.40)"),
             "executed_frac": (executed / sec / 1e12) / peak if sec > 0 else 0.0,
             "executed_mfma_tflops": executed / sec / 1e12 if sec > 0 else 0.0,
             "f8c_flop_share": f8c_alg / conv["flops"] if conv["flops"] else 0.0,
