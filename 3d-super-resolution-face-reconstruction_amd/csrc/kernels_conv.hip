@@ -1268,12 +1268,16 @@ __global__ __launch_bounds__(512, (BN == 64 && MS == 16 && BM == 128) ? 6 : 4) v
                 constexpr int tap = decltype(tc)::value;
                 constexpr int dy = tap / KS, dx = tap % KS;
                 const bool feed = !(SR3_DBG(p) & 1) || k == 0;      // experiment: operands only for the first K-step
+                // experiment bit 7 (timing only, results wrong): every other block issues no weight DMA after its first K-step —
+                // what the launch would cost if co-resident blocks SHARED their weight tiles (37 % fewer L2 bytes on a 128x128
+                // tile) without being tied to each other's barriers (profiles/README.md finding 72)
+                const bool feed_b = feed && (!(SR3_DBG(p) & 128) || !(blockIdx.x & 1) || k == 0);
                 // The B tile of this K-step goes out FIRST: the consumers wait for it at the very next barrier. The A
                 // halo group issued at dx == 1 is not read before the K-step after next, so it goes out behind the B
                 // tile and stays in flight across this K-step's barrier (counted wait: the wave's nh youngest DMAs).
                 float *Bd = Bring + (k & 1) * BSTG + w * 256;
                 const char *wb = wbase + (size_t)tap * tapstride * 4;
-                if (feed) {
+                if (feed_b) {
                     static_for<BR>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         dma16s<true>(wb, vB[i], Bd + i * 1024);
